@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE implementation itself.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference is copied
+into this repo: the script parses /root/reference/backend/app.py at run time, pulls out the one
+ClassDef named `DenoiseGenerator` (app.py:39-103; the rest of the module needs torchvision /
+fastapi and is not executed), instantiates it, loads the portable synthetic weights of
+celebrity_image_denoiser_amd.synth, and records inputs, every intermediate the module exposes
+(forward hooks on down1, pool1, down2, pool2, bottleneck, up2, upconv2, up1, upconv1) and the output.
+
+Fixtures written (float32, numpy .npz):
+  tiny_<wset>_<H>x<W>.npz    N=2 16x16, N=2 20x24, N=1 13x18 (crop path), N=1 4x4, N=1 7x9:
+                             input + all stages + out
+  full_<wset>_128.npz        N=2 128x128: out only (input regenerated from synth; sha256 recorded)
+  stats.json                 N=4 128x128 and N=1 256x256: per-stage sum / sumsq / min / max /
+                             16 sampled elements, both weight sets; plus psnr figures
+with <wset> in {default, hot}.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import ast
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from celebrity_image_denoiser_amd import synth  # noqa: E402
+
+REF_APP = "/root/reference/backend/app.py"
+STAGES = ("down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1", "upconv1")
+
+
+def lift_reference_class():
+    with open(REF_APP, "r") as f:
+        tree = ast.parse(f.read(), REF_APP)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DenoiseGenerator"]
+    assert len(cls) == 1
+    ns = {"torch": torch, "nn": nn}
+    exec(compile(ast.Module(body=cls, type_ignores=[]), REF_APP, "exec"), ns)
+    return ns["DenoiseGenerator"]
+
+
+def run(model, x):
+    rec = {}
+    hooks = [getattr(model, s).register_forward_hook(lambda m, i, o, s=s: rec.__setitem__(s, o.detach().clone()))
+             for s in STAGES]
+    with torch.no_grad():
+        out = model(torch.from_numpy(x))
+    for h in hooks:
+        h.remove()
+    rec["out"] = out
+    return {k: v.numpy() for k, v in rec.items()}
+
+
+def sample_idx(n, k=16):
+    return [int(i) for i in (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % n]
+
+
+def stats_of(a):
+    f = a.reshape(-1).astype(np.float64)
+    idx = sample_idx(f.size)
+    return {"shape": list(a.shape), "sum": float(f.sum()), "sumsq": float((f * f).sum()),
+            "min": float(f.min()), "max": float(f.max()), "idx": idx, "samples": [float(a.reshape(-1)[i]) for i in idx]}
+
+
+def psnr(a, b):
+    mse = ((a.astype(np.float64) - b.astype(np.float64)) ** 2).reshape(a.shape[0], -1).mean(axis=1)
+    return float(np.mean(10.0 * np.log10(4.0 / mse)))
+
+
+def main():
+    torch.set_num_threads(8)
+    cls = lift_reference_class()
+    stats = {"torch": torch.__version__, "reference": "backend/app.py:39-103 DenoiseGenerator (lifted by AST)"}
+    for wset in ("default", "hot"):
+        sd = synth.make_state_dict(wset)
+        model = cls()
+        missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        model.eval()
+        assert sum(p.numel() for p in model.parameters()) == 1827587, missing
+        for n, h, w, first in ((2, 16, 16, 0), (2, 20, 24, 10), (1, 13, 18, 20), (1, 4, 4, 30), (1, 7, 9, 40)):
+            x, clean, _ = synth.make_batch(n, h, w, first)
+            r = run(model, x)
+            np.savez_compressed(os.path.join(HERE, f"tiny_{wset}_{h}x{w}.npz"), x=x, **r)
+        x, clean, _ = synth.make_batch(2, 128, 128, 100)
+        r = run(model, x)
+        np.savez_compressed(os.path.join(HERE, f"full_{wset}_128.npz"), out=r["out"],
+                            x_sha256=np.frombuffer(hashlib.sha256(x.tobytes()).digest(), dtype=np.uint8))
+        for tag, (n, h, w, first) in {"n4_128": (4, 128, 128, 200), "n1_256": (1, 256, 256, 300)}.items():
+            x, clean, _ = synth.make_batch(n, h, w, first)
+            r = run(model, x)
+            stats[f"{wset}_{tag}"] = {
+                "n": n, "h": h, "w": w, "first_index": first,
+                "x_sha256": hashlib.sha256(x.tobytes()).hexdigest(),
+                "stages": {k: stats_of(v) for k, v in r.items()},
+                "psnr_out_vs_clean": psnr(r["out"], clean), "psnr_noisy_vs_clean": psnr(x, clean),
+            }
+        # batch-(in)dependence of the reference forward: ATen may pick another conv algorithm per shape
+        x, _, _ = synth.make_batch(3, 16, 16, 50)
+        with torch.no_grad():
+            yb = model(torch.from_numpy(x)).numpy()
+            ys = np.concatenate([model(torch.from_numpy(x[i:i + 1])).numpy() for i in range(3)])
+        stats[f"{wset}_batched_vs_per_sample_maxabs"] = float(np.abs(yb - ys).max())
+        # run-to-run determinism and thread-count independence of the reference on this host
+        with torch.no_grad():
+            y2 = model(torch.from_numpy(x)).numpy()
+            torch.set_num_threads(1)
+            y1t = model(torch.from_numpy(x)).numpy()
+            torch.set_num_threads(8)
+        stats[f"{wset}_rerun_maxabs"] = float(np.abs(yb - y2).max())
+        stats[f"{wset}_1thread_vs_8threads_maxabs"] = float(np.abs(yb - y1t).max())
+        # fp32 reference vs the same module in float64: how far the reference itself is from exact
+        m64 = cls().double()
+        m64.load_state_dict({k: torch.from_numpy(v).double() for k, v in sd.items()})
+        xb, _, _ = synth.make_batch(2, 128, 128, 100)
+        with torch.no_grad():
+            y64 = m64(torch.from_numpy(xb).double()).numpy()
+            y32 = model(torch.from_numpy(xb)).numpy()
+        stats[f"{wset}_fp32_vs_fp64_maxabs_128"] = float(np.abs(y32.astype(np.float64) - y64).max())
+    with open(os.path.join(HERE, "stats.json"), "w") as f:
+        json.dump(stats, f, indent=1)
+    print("wrote fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()
