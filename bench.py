@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the denoise forward at batch 256, 128x128x3, fp32, per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of the hot path over one batch of 256 synthetic 128x128x3 Gaussian-noised
+images per GPU (BASELINE.json configs[1]; with N GPUs the global batch is 256*N — configs[2] at
+N=8 — sharded contiguously, weak scaling), inputs already resident in HBM.  Rank 0 loads the
+(seeded synthetic) weights and ONE RCCL broadcast of the packed blob distributes them; the
+forward itself has no collective.  Prints one JSON line on rank 0.
+
+Extra objects on that line:
+  roofline      dominant kernel of the forward: algorithmic FLOPs per launch / its mean launch
+                duration from HIP events recorded on the launch stream during the timed steps;
+                peak = gfx950 dense fp32 matrix rate (157.3 TFLOP/s)
+  cpu_baseline  (N=1 only) the CPU oracle = the reference's forward re-stated on the ATen CPU
+                operators the reference itself calls, timed on this host's cores on a bounded sample
+  layers        every launch: ms, TFLOP/s, GB/s, fraction of its own (mfma|hbm) roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import celebrity_image_denoiser_amd as cid  # noqa: E402
+from celebrity_image_denoiser_amd import dist as cdist  # noqa: E402
+from celebrity_image_denoiser_amd import synth  # noqa: E402
+from celebrity_image_denoiser_amd.generator import launch_table  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0          # spec; ~6300 GB/s achievable
+
+
+def cpu_baseline(sd, budget_s: float = 15.0):
+    """Time the CPU oracle (kind "port": the reference forward re-stated on ATen CPU ops) on a bounded
+    sample of the same workload: batches of 32 images 128x128 until ~budget_s of CPU work."""
+    from oracle import torch_oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, _, _ = synth.make_batch(32, 128, 128, first_index=5000)
+    torch_oracle.forward(sd, x[:4])   # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    torch_oracle.forward(sd, x)
+    t1 = time.perf_counter() - t0
+    reps = int(max(1, min(16, budget_s / max(t1, 1e-3) - 1)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch_oracle.forward(sd, x)
+    dt = time.perf_counter() - t0
+    out = {"value": round(32 * reps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{reps} x batch of 32 images 128x128x3 fp32 through oracle/torch_oracle.py (ATen CPU conv2d/conv_transpose2d/max_pool2d, the operators the reference module calls), {dt:.1f} s"}
+    try:   # second opinion: the dependency-free C restatement (OpenMP), 8 images
+        from oracle import c_oracle
+
+        t0 = time.perf_counter()
+        c_oracle.forward(sd, x[:8])
+        out["c_oracle_images_per_sec"] = round(8 / (time.perf_counter() - t0), 2)
+    except Exception as e:  # pragma: no cover
+        out["c_oracle_error"] = str(e)[:100]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--weights", default="default", choices=["default", "hot"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, S = args.batch_per_gpu, args.size
+    sd = synth.make_state_dict(args.weights)
+    # rank 0 owns the checkpoint; everyone else starts from its own random init and receives the blob
+    model = cid.load(sd if rank == 0 else None, device=dev, strict=True)
+    if world > 1:
+        cdist.broadcast_weights(model, src=0)
+
+    begin, end = cdist.shard_range(B * world, rank, world)
+    x_host, clean_host, _ = synth.make_batch(end - begin, S, S, first_index=begin)
+    x = torch.from_numpy(x_host).to(dev)
+    torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    y = None
+    for _ in range(args.warmup):
+        y = model(x)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    model.timing_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = model(x)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launch_ms, nfw = model.timing_end()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        table = launch_table(end - begin, S, S)
+        layers = []
+        for (name, kern, flops, nbytes), ms_sum in zip(table, launch_ms):
+            ms = ms_sum / max(nfw, 1)
+            tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+            t_ideal = max(flops / (PEAK_F32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9))
+            bound = "mfma" if flops / (PEAK_F32_MFMA_TFLOPS * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9) else "hbm"
+            layers.append({"layer": name, "kernel": kern, "ms": round(ms, 4), "tflops": round(tf, 2), "gbs": round(gbs, 1),
+                           "bound": bound, "frac": round(t_ideal / (ms * 1e-3), 4)})
+        dom = max(range(len(layers)), key=lambda i: layers[i]["ms"])
+        d = layers[dom]
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/collect_pmc.sh (separate --pmc passes)
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(d["kernel"])
+            except Exception:
+                traffic = None
+        if d["bound"] == "mfma":
+            roof = {"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic}
+        else:
+            roof = {"bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
+        roof.update({"kernel": d["kernel"], "layer": d["layer"], "avg_launch_ms": d["ms"], "launches_timed": nfw,
+                     "flops_per_launch": table[dom][2], "bytes_per_launch": table[dom][3]})
+        total_flops = sum(r[2] for r in table)
+        res = {
+            "metric": "images/sec at batch 256, 128x128x3, fp32 denoise forward",
+            "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: batch={B} per GPU, {S}x{S}x3 fp32 forward, HIP conv kernels"
+                                   + (f" (global batch {B * world} sharded over {world} GPUs, configs[2] shape)" if world > 1 else ""),
+                       "global_batch": B * world, "image": [S, S, 3], "weights": f"synthetic seeded ({args.weights})",
+                       "parallelism": f"dp{world}", "inputs": "resident in HBM"},
+            "whole_net_tflops": round(total_flops * args.steps / elapsed / 1e12 * 1.0, 2),
+            "whole_net_frac_of_f32_mfma_peak": round(total_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof,
+            "layers": layers,
+        }
+        # parity spot-check on the timed output: 2 images vs the CPU oracle
+        try:
+            from oracle import torch_oracle
+
+            ref = torch_oracle.forward(sd, x_host[:2]).numpy()
+            got = y[:2].cpu().numpy()
+            res["parity"] = {"max_abs_err_vs_cpu_oracle": float(np.abs(got - ref).max()),
+                             "psnr_delta_db": abs(cid.psnr(got, clean_host[:2]) - cid.psnr(ref, clean_host[:2])),
+                             "tolerance": "max|delta|<=1e-5, psnr_delta<=0.01 dB"}
+        except Exception as e:  # pragma: no cover
+            res["parity"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

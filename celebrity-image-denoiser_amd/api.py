@@ -1,0 +1,93 @@
+"""model-load / denoise(image_batch) -> image_batch convenience layer.
+
+Restates, for the build's own class, what the reference does around its module:
+  * load_state_safely            reference backend/app.py:257-274 (+ the fallback at :327-336)
+  * the value contract           reference backend/app.py:401-406 (input (u8/255-0.5)/0.5), :434-435
+  * iterated denoising           reference backend/trainingcode/denoise_gan_code/denoise_eavl_iter.py:93-96
+"""
+from __future__ import annotations
+
+import logging
+from typing import Mapping, Optional, Sequence, Union
+
+import torch
+
+from .generator import DenoiseGenerator
+
+logger = logging.getLogger("cid")
+
+
+def extract_state_dict(ckpt, key_candidates: Sequence[str] = ("generator", "state_dict", "G")) -> Mapping:
+    """Checkpoint object -> flat state_dict, like the reference loader: if the checkpoint is a dict
+    holding a dict under one of `key_candidates` (the trainer saves {"generator": sd, ...},
+    training.py:359-361) use that, else the object itself; then drop a leading "module." from
+    every key (DataParallel checkpoints)."""
+    state = ckpt
+    if isinstance(ckpt, dict):
+        for k in key_candidates:
+            if k in ckpt and isinstance(ckpt[k], dict):
+                state = ckpt[k]
+                break
+    out = {}
+    for k, v in state.items():
+        if isinstance(k, str) and k.startswith("module."):
+            k = k.replace("module.", "")
+        out[k] = v
+    return out
+
+
+def load_state_safely(model: torch.nn.Module, checkpoint_path: str,
+                      key_candidates: Sequence[str] = ("generator", "state_dict", "G")) -> None:
+    """torch.load -> extract_state_dict -> load_state_dict(strict=False) -> eval()  (app.py:257-274)."""
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    model.load_state_dict(extract_state_dict(ckpt, key_candidates), strict=False)
+    model.eval()
+    logger.info("Loaded PyTorch weights from %s", checkpoint_path)
+
+
+def load(source: Union[str, Mapping, None] = None, device: Optional[Union[str, torch.device]] = None,
+         strict: bool = False) -> DenoiseGenerator:
+    """Build a DenoiseGenerator on `device` (default: current GPU) and load weights from a checkpoint
+    path, a checkpoint dict or a state_dict.  `source=None` keeps the random initialisation — the
+    state the reference server runs in when its checkpoint is missing (app.py:333-336)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if device is None or torch.device(device).type != "cuda":
+        raise RuntimeError("celebrity_image_denoiser_amd.load: an AMD GPU is required (no CPU fallback)")
+    model = DenoiseGenerator()
+    if isinstance(source, str):
+        ckpt = torch.load(source, map_location="cpu", weights_only=False)
+        model.load_state_dict(extract_state_dict(ckpt), strict=strict)
+    elif source is not None:
+        sd = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in extract_state_dict(source).items()}
+        model.load_state_dict(sd, strict=strict)
+    model.to(device).eval()
+    model.pack_weights()
+    return model
+
+
+def denoise(model: DenoiseGenerator, image_batch: torch.Tensor, iterations: int = 1,
+            max_batch: Optional[int] = None) -> torch.Tensor:
+    """image_batch -> image_batch: fp32 [N,3,H,W] in [-1,1] -> fp32 [N,3,4*(H//4),4*(W//4)] in (-1,1).
+
+    The batch may live on the host or the GPU; the result comes back where the input was.
+    `iterations` feeds the output back in, on the device (denoise_eavl_iter.py:93-96);
+    `max_batch` splits very large batches to bound the activation arena."""
+    if iterations < 1:
+        raise ValueError("iterations must be >= 1")
+    dev = next(model.parameters()).device
+    src_dev = image_batch.device
+    outs = []
+    step = max_batch or image_batch.shape[0]
+    for i in range(0, image_batch.shape[0], step):
+        x = image_batch[i:i + step].to(dev, torch.float32, non_blocking=True)
+        for _ in range(iterations):
+            x = model(x)
+        outs.append(x)
+    y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+    return y.to(src_dev)
+
+
+def to_unit_range(y: torch.Tensor) -> torch.Tensor:
+    """The reference's view transform for tanh-range outputs: y*0.5+0.5 clamped to [0,1] (app.py:435)."""
+    return (y * 0.5 + 0.5).clamp(0, 1)

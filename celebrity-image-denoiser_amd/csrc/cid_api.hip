@@ -1,0 +1,476 @@
+// cid_api.hip — the C ABI of include/cid.h: weight repacking, workspace planning and the launch
+// sequence of one forward.  Host code; the device kernels are in conv_kernels.h.
+//
+// Layer table = the reference module's declaration order, backend/app.py:42-78.
+#include "../../include/cid.h"
+#include "conv_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+using namespace cid;
+
+enum Kind { HEAD, CONV, CONVT, TAIL };
+struct LayerDef { const char* name; Kind kind; int cin, cout; };
+constexpr int NL = 12;
+const LayerDef kLayers[NL] = {
+    {"down1.0", HEAD, 3, 64},        {"down1.2", CONV, 64, 64},        {"down2.0", CONV, 64, 128},
+    {"down2.2", CONV, 128, 128},     {"bottleneck.0", CONV, 128, 256}, {"bottleneck.2", CONV, 256, 256},
+    {"up2", CONVT, 256, 128},        {"upconv2.0", CONV, 256, 128},    {"upconv2.2", CONV, 128, 128},
+    {"up1", CONVT, 128, 64},         {"upconv1.0", CONV, 128, 64},     {"upconv1.2", TAIL, 64, 3},
+};
+const char* kKernelNames[NL] = {
+    "k_conv_head", "k_gemm_conv<64, 64, 1>", "k_gemm_conv<64, 128, 0>", "k_gemm_conv<128, 128, 1>",
+    "k_gemm_conv<128, 256, 0>", "k_gemm_conv<256, 256, 0>", "k_gemm_conv<256, 128, 2>", "k_gemm_conv<256, 128, 0>",
+    "k_gemm_conv<128, 128, 0>", "k_gemm_conv<128, 64, 2>", "k_gemm_conv<128, 64, 0>", "k_conv_tail",
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t ref_weight_count(const LayerDef& L) { return (size_t)L.cin * L.cout * (L.kind == CONVT ? 4 : 9); }
+size_t packed_weight_count(const LayerDef& L) {
+    switch (L.kind) {
+        case HEAD: return 2 * 14 * 64;
+        case TAIL: return 2 * 9 * 8 * 12;
+        default: return ref_weight_count(L);
+    }
+}
+
+// float offsets of each layer's packed weights / bias inside the blob; segments 256-byte aligned
+struct BlobLayout {
+    size_t w_off[NL], b_off[NL], total;
+    BlobLayout() {
+        size_t o = 0;
+        for (int l = 0; l < NL; ++l) {
+            w_off[l] = o; o = align_up(o + packed_weight_count(kLayers[l]), 64);
+            b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
+        }
+        total = o;
+    }
+};
+const BlobLayout kBlob;
+
+// Index in the packed segment of reference weight element (co, ci, kh, kw) of layer L.
+// GEMM layers: [nb][chunk][tap][group g][ns][lane = 32*h + j][e] with
+//   ci = 32*chunk + 8*g + 4*h + e  and  n' = 64*nb + 32*ns + j  (n' = co, or tap*COUT + co for convT)
+// — lane (h, j) of v_mfma_f32_32x32x2_f32 holds B[k = h][col = j]; e walks the 4 MFMAs of a group.
+size_t packed_index(const LayerDef& L, int co, int ci, int kh, int kw) {
+    switch (L.kind) {
+        case HEAD: {
+            const int k = ci * 9 + kh * 3 + kw, s = k >> 1, h = k & 1;
+            return (size_t)((co >> 5) * 14 + s) * 64 + h * 32 + (co & 31);
+        }
+        case TAIL: {
+            const int tap = kh * 3 + kw, ck = ci >> 5, g = (ci >> 2) & 7, e = ci & 3;
+            return (size_t)((ck * 9 + tap) * 8 + g) * 12 + co * 4 + e;
+        }
+        case CONV:
+        case CONVT: {
+            const int taps = L.kind == CONV ? 9 : 1;
+            const int tap = L.kind == CONV ? kh * 3 + kw : 0;
+            const int np = L.kind == CONV ? co : (kh * 2 + kw) * L.cout + co;
+            const int nb = np >> 6, ns = (np >> 5) & 1, j = np & 31;
+            const int ck = ci >> 5, g = (ci >> 3) & 3, h = (ci >> 2) & 1, e = ci & 3;
+            const int nchunk = L.cin / 32;
+            return ((((size_t)(nb * nchunk + ck) * taps + tap) * 4 + g) * 2 + ns) * 256 + (h * 32 + j) * 4 + e;
+        }
+    }
+    return 0;
+}
+// Index of (co, ci, kh, kw) in the reference tensor: Conv2d [Cout,Cin,3,3]; ConvTranspose2d [Cin,Cout,2,2].
+size_t ref_index(const LayerDef& L, int co, int ci, int kh, int kw) {
+    if (L.kind == CONVT) return (((size_t)ci * L.cout + co) * 2 + kh) * 2 + kw;
+    return (((size_t)co * L.cin + ci) * 3 + kh) * 3 + kw;
+}
+
+struct Dims {
+    int N, H, W, H1, W1, H2, W2, Hu2, Wu2, Hu1, Wu1;
+};
+bool make_dims(int N, int H, int W, Dims& d) {
+    if (N < 1 || H < 4 || W < 4) return false;
+    d.N = N; d.H = H; d.W = W;
+    d.H1 = H / 2; d.W1 = W / 2; d.H2 = d.H1 / 2; d.W2 = d.W1 / 2;       // floor-mode pools, app.py:48,56
+    d.Hu2 = 2 * d.H2; d.Wu2 = 2 * d.W2; d.Hu1 = 2 * d.Hu2; d.Wu1 = 2 * d.Wu2;  // x2 transposed convs, app.py:65,73
+    return true;
+}
+
+// activation arena (floats), NHWC
+enum Buf { T0, CAT1, P1, T1, CAT2, P2, T2, BT, T3, D2, T4, NBUF };
+struct Plan { size_t off[NBUF]; size_t total_bytes; };
+Plan make_plan(const Dims& d) {
+    const size_t s0 = (size_t)d.N * d.H * d.W, s1 = (size_t)d.N * d.H1 * d.W1, s2 = (size_t)d.N * d.H2 * d.W2;
+    const size_t su2 = (size_t)d.N * d.Hu2 * d.Wu2, su1 = (size_t)d.N * d.Hu1 * d.Wu1;
+    const size_t sz[NBUF] = {s0 * 64, su1 * 128, s1 * 64, s1 * 128, su2 * 256, s2 * 128, s2 * 256, s2 * 256, su2 * 128, su2 * 128, su1 * 64};
+    Plan p; size_t o = 0;
+    for (int b = 0; b < NBUF; ++b) { p.off[b] = o; o = align_up(o + sz[b], 64); }
+    p.total_bytes = o * sizeof(float);
+    return p;
+}
+
+}  // namespace
+
+struct cid_handle_s {
+    std::vector<float> staging;        // packed host blob
+    bool have[NL][2];
+    const float* dev_blob = nullptr;
+    std::string err;
+    std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
+    int tev_forwards = 0, tev_used = 0;
+    cid_handle_s() : staging(kBlob.total, 0.f) { std::memset(have, 0, sizeof(have)); }
+};
+
+namespace {
+
+int fail(cid_handle_t h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+bool find_key(const char* key, int& layer, int& is_bias) {
+    if (!key) return false;
+    const std::string k(key);
+    for (int l = 0; l < NL; ++l) {
+        const std::string n(kLayers[l].name);
+        if (k == n + ".weight") { layer = l; is_bias = 0; return true; }
+        if (k == n + ".bias") { layer = l; is_bias = 1; return true; }
+    }
+    return false;
+}
+
+template <typename F>
+void for_each_weight(const LayerDef& L, F f) {
+    const int kk = L.kind == CONVT ? 2 : 3;
+    for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int kh = 0; kh < kk; ++kh)
+                for (int kw = 0; kw < kk; ++kw) f(co, ci, kh, kw);
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct TileGrid { int tx, ty, total, per_xcd; };
+TileGrid tiles_for(int N, int Hc, int Wc) {
+    TileGrid g;
+    g.tx = cdiv(Wc, TILE_W); g.ty = cdiv(Hc, TILE_H);
+    g.total = N * g.tx * g.ty;
+    g.per_xcd = cdiv(g.total, 8);
+    return g;
+}
+
+template <int CIN, int COUT, int MODE>
+hipError_t launch_gemm(hipStream_t s, const float* blob, int layer, const float* in, int Hin, int Win, int in_ps,
+                       float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
+    GemmConvArgs a;
+    a.in = in; a.w = blob + kBlob.w_off[layer]; a.bias = blob + kBlob.b_off[layer];
+    a.out = out; a.pool = pool;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps;
+    a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
+    const TileGrid g = tiles_for(N, Hc, Wc);
+    a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+    constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
+    hipLaunchKernelGGL((k_gemm_conv<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid) {
+    hipLaunchKernelGGL(k_conv_head, dim3(grid), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid) {
+    hipLaunchKernelGGL(k_conv_tail, dim3(grid), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W, void* ws, size_t ws_bytes,
+                hipStream_t s, hipEvent_t* ev /* NL+1 events or null */) {
+    if (!h) return CID_ERR_INVALID;
+    if (!in || !out || !ws) return fail(h, CID_ERR_INVALID, "cid_forward: null pointer");
+    if (!h->dev_blob) return fail(h, CID_ERR_STATE, "cid_forward: no device weights attached (call cid_upload_weights or cid_attach_weights)");
+    Dims d;
+    if (!make_dims(N, H, W, d)) {
+        char m[128];
+        std::snprintf(m, sizeof m, "cid_forward: input [%d,3,%d,%d] not accepted: N >= 1 and H, W >= 4 required (output size is too small)", N, H, W);
+        return fail(h, CID_ERR_SHAPE, m);
+    }
+    const Plan p = make_plan(d);
+    if (ws_bytes < p.total_bytes) return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace smaller than cid_workspace_bytes()");
+    if (((uintptr_t)ws & 255) || ((uintptr_t)in & 15) || ((uintptr_t)h->dev_blob & 255))
+        return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace/weights must be 256-byte aligned, input 16-byte aligned");
+    float* base = static_cast<float*>(ws);
+    float* B[NBUF];
+    for (int b = 0; b < NBUF; ++b) B[b] = base + p.off[b];
+    const float* blob = h->dev_blob;
+    hipError_t e = hipSuccess;
+    int li = 0;
+#define STEP(call)                                                                         \
+    do {                                                                                   \
+        if (ev && hipEventRecord(ev[li], s) != hipSuccess) e = hipErrorUnknown;            \
+        if (e == hipSuccess) e = (call);                                                   \
+        if (e != hipSuccess) {                                                             \
+            return fail(h, CID_ERR_HIP, std::string("launch '") + kLayers[li].name + "' failed: " + hipGetErrorString(e)); \
+        }                                                                                  \
+        ++li;                                                                              \
+    } while (0)
+
+    {   // down1[0]: Conv 3->64 + ReLU, NCHW in -> NHWC t0            app.py:43-44
+        HeadArgs a;
+        a.in = in; a.w = blob + kBlob.w_off[0]; a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
+        a.N = N; a.H = H; a.W = W;
+        const TileGrid g = tiles_for(N, H, W);
+        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        STEP(launch_head(s, a, 8 * g.per_xcd));
+    }
+    // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
+    STEP((launch_gemm<64, 64, 1>(s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
+    // down2[0] + ReLU                                                                    app.py:51-52
+    STEP((launch_gemm<64, 128, 0>(s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
+    // down2[2] + ReLU -> e2 into cat2[:, 128:256] (cropped), pool2 -> p2                 app.py:53-56,90-93
+    STEP((launch_gemm<128, 128, 1>(s, blob, 3, B[T1], d.H1, d.W1, 128, B[CAT2], 256, 128, d.Hu2, d.Wu2, d.Hu2, d.Wu2, B[P2], N)));
+    // bottleneck                                                                         app.py:59-62
+    STEP((launch_gemm<128, 256, 0>(s, blob, 4, B[P2], d.H2, d.W2, 128, B[T2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_gemm<256, 256, 0>(s, blob, 5, B[T2], d.H2, d.W2, 256, B[BT], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    // up2: ConvT 256->128 -> cat2[:, 0:128]                                              app.py:65,89
+    STEP((launch_gemm<256, 128, 2>(s, blob, 6, B[BT], d.H2, d.W2, 256, B[CAT2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    // upconv2                                                                            app.py:67-70
+    STEP((launch_gemm<256, 128, 0>(s, blob, 7, B[CAT2], d.Hu2, d.Wu2, 256, B[T3], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_gemm<128, 128, 0>(s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    // up1: ConvT 128->64 -> cat1[:, 0:64]                                                app.py:73,96
+    STEP((launch_gemm<128, 64, 2>(s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    // upconv1[0] + ReLU                                                                  app.py:75-76
+    STEP((launch_gemm<128, 64, 0>(s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
+    {   // upconv1[2] + tanh, NHWC t4 -> NCHW out                                         app.py:77,103
+        TailArgs a;
+        a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
+        a.N = N; a.H = d.Hu1; a.W = d.Wu1;
+        const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
+        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        STEP(launch_tail(s, a, 8 * g.per_xcd));
+    }
+#undef STEP
+    if (ev && hipEventRecord(ev[NL], s) != hipSuccess) return fail(h, CID_ERR_HIP, "hipEventRecord failed");
+    return CID_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cid_version(void) { return "cid 0.1.0 (gfx950, fp32 MFMA implicit-GEMM)"; }
+
+int cid_create(cid_handle_t* out) {
+    if (!out) return CID_ERR_INVALID;
+    *out = new (std::nothrow) cid_handle_s();
+    return *out ? CID_OK : CID_ERR_INVALID;
+}
+
+void cid_destroy(cid_handle_t h) {
+    if (h) for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+const char* cid_last_error(cid_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+const char* cid_param_key(int i) {
+    static std::string keys[CID_NUM_PARAMS];
+    if (i < 0 || i >= CID_NUM_PARAMS) return nullptr;
+    if (keys[i].empty()) keys[i] = std::string(kLayers[i / 2].name) + ((i & 1) ? ".bias" : ".weight");
+    return keys[i].c_str();
+}
+
+int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!h) return CID_ERR_INVALID;
+    if (!key || !data || !shape) return fail(h, CID_ERR_INVALID, "cid_set_weight: null argument");
+    int l, is_bias;
+    if (!find_key(key, l, is_bias)) return fail(h, CID_ERR_KEY, std::string("unexpected key '") + key + "' in state_dict");
+    const LayerDef& L = kLayers[l];
+    int64_t want[4]; int wn;
+    if (is_bias) { want[0] = L.cout; wn = 1; }
+    else if (L.kind == CONVT) { want[0] = L.cin; want[1] = L.cout; want[2] = 2; want[3] = 2; wn = 4; }
+    else { want[0] = L.cout; want[1] = L.cin; want[2] = 3; want[3] = 3; wn = 4; }
+    bool ok = ndim == wn;
+    for (int i = 0; ok && i < wn; ++i) ok = shape[i] == want[i];
+    if (!ok) {
+        std::string m = std::string("size mismatch for ") + key + ": expected [";
+        for (int i = 0; i < wn; ++i) m += (i ? "," : "") + std::to_string(want[i]);
+        m += "], got [";
+        for (int i = 0; i < ndim; ++i) m += (i ? "," : "") + std::to_string(shape[i]);
+        return fail(h, CID_ERR_SHAPE, m + "]");
+    }
+    if (is_bias) {
+        std::memcpy(h->staging.data() + kBlob.b_off[l], data, sizeof(float) * L.cout);
+    } else {
+        float* dst = h->staging.data() + kBlob.w_off[l];
+        for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
+    }
+    h->have[l][is_bias] = true;
+    return CID_OK;
+}
+
+int cid_get_weight(cid_handle_t h, const char* key, float* out, size_t count) {
+    if (!h) return CID_ERR_INVALID;
+    if (!key || !out) return fail(h, CID_ERR_INVALID, "cid_get_weight: null argument");
+    int l, is_bias;
+    if (!find_key(key, l, is_bias)) return fail(h, CID_ERR_KEY, std::string("unknown key '") + key + "'");
+    const LayerDef& L = kLayers[l];
+    const size_t need = is_bias ? (size_t)L.cout : ref_weight_count(L);
+    if (count != need) return fail(h, CID_ERR_SHAPE, std::string("cid_get_weight: wrong element count for ") + key);
+    if (is_bias) {
+        std::memcpy(out, h->staging.data() + kBlob.b_off[l], sizeof(float) * L.cout);
+    } else {
+        const float* src = h->staging.data() + kBlob.w_off[l];
+        for_each_weight(L, [&](int co, int ci, int kh, int kw) { out[ref_index(L, co, ci, kh, kw)] = src[packed_index(L, co, ci, kh, kw)]; });
+    }
+    return CID_OK;
+}
+
+int cid_missing_weights(cid_handle_t h, int* missing) {
+    if (!h || !missing) return CID_ERR_INVALID;
+    int m = 0;
+    for (int l = 0; l < NL; ++l) m += !h->have[l][0] + !h->have[l][1];
+    *missing = m;
+    return CID_OK;
+}
+
+size_t cid_packed_weights_bytes(void) { return kBlob.total * sizeof(float); }
+
+int cid_upload_weights(cid_handle_t h, void* device_blob, void* stream) {
+    if (!h) return CID_ERR_INVALID;
+    if (!device_blob) return fail(h, CID_ERR_INVALID, "cid_upload_weights: null device pointer");
+    if ((uintptr_t)device_blob & 255) return fail(h, CID_ERR_WORKSPACE, "cid_upload_weights: blob must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(device_blob, h->staging.data(), kBlob.total * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // staging is pageable host memory owned by the handle
+    if (e != hipSuccess) return fail(h, CID_ERR_HIP, std::string("cid_upload_weights: ") + hipGetErrorString(e));
+    h->dev_blob = static_cast<const float*>(device_blob);
+    return CID_OK;
+}
+
+int cid_export_packed(cid_handle_t h, void* host_out, size_t bytes) {
+    if (!h) return CID_ERR_INVALID;
+    if (!host_out) return fail(h, CID_ERR_INVALID, "cid_export_packed: null pointer");
+    if (bytes != kBlob.total * sizeof(float)) return fail(h, CID_ERR_SHAPE, "cid_export_packed: size != cid_packed_weights_bytes()");
+    std::memcpy(host_out, h->staging.data(), bytes);
+    return CID_OK;
+}
+
+int cid_import_packed(cid_handle_t h, const void* host_in, size_t bytes) {
+    if (!h) return CID_ERR_INVALID;
+    if (!host_in) return fail(h, CID_ERR_INVALID, "cid_import_packed: null pointer");
+    if (bytes != kBlob.total * sizeof(float)) return fail(h, CID_ERR_SHAPE, "cid_import_packed: size != cid_packed_weights_bytes()");
+    std::memcpy(h->staging.data(), host_in, bytes);
+    std::memset(h->have, 1, sizeof(h->have));
+    return CID_OK;
+}
+
+int cid_attach_weights(cid_handle_t h, const void* device_blob) {
+    if (!h) return CID_ERR_INVALID;
+    if (!device_blob) return fail(h, CID_ERR_INVALID, "cid_attach_weights: null device pointer");
+    if ((uintptr_t)device_blob & 255) return fail(h, CID_ERR_WORKSPACE, "cid_attach_weights: blob must be 256-byte aligned");
+    h->dev_blob = static_cast<const float*>(device_blob);
+    return CID_OK;
+}
+
+int cid_out_shape(int H, int W, int* Ho, int* Wo) {
+    if (!Ho || !Wo) return CID_ERR_INVALID;
+    if (H < 4 || W < 4) return CID_ERR_SHAPE;
+    *Ho = 4 * (H / 4);
+    *Wo = 4 * (W / 4);
+    return CID_OK;
+}
+
+int cid_workspace_bytes(int N, int H, int W, size_t* bytes) {
+    if (!bytes) return CID_ERR_INVALID;
+    Dims d;
+    if (!make_dims(N, H, W, d)) return CID_ERR_SHAPE;
+    *bytes = make_plan(d).total_bytes;
+    return CID_OK;
+}
+
+int cid_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    hipEvent_t* ev = nullptr;
+    if (h && h->tev_used < h->tev_forwards) ev = h->tev.data() + (size_t)h->tev_used * (NL + 1);
+    const int rc = run_forward(h, in, out, N, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), ev);
+    if (ev && rc == CID_OK) ++h->tev_used;
+    return rc;
+}
+
+int cid_timing_begin(cid_handle_t h, int max_forwards) {
+    if (!h) return CID_ERR_INVALID;
+    if (max_forwards < 1 || max_forwards > 4096) return fail(h, CID_ERR_INVALID, "cid_timing_begin: max_forwards out of range");
+    if (!h->tev.empty()) return fail(h, CID_ERR_STATE, "cid_timing_begin: timing already armed");
+    h->tev.resize((size_t)max_forwards * (NL + 1));
+    for (size_t i = 0; i < h->tev.size(); ++i)
+        if (hipEventCreate(&h->tev[i]) != hipSuccess) {
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(h->tev[j]);
+            h->tev.clear();
+            return fail(h, CID_ERR_HIP, "cid_timing_begin: hipEventCreate failed");
+        }
+    h->tev_forwards = max_forwards;
+    h->tev_used = 0;
+    return CID_OK;
+}
+
+int cid_timing_end(cid_handle_t h, void* stream, float* launch_ms_sum, int* forwards) {
+    if (!h) return CID_ERR_INVALID;
+    if (!launch_ms_sum || !forwards) return fail(h, CID_ERR_INVALID, "cid_timing_end: null pointer");
+    if (h->tev.empty()) return fail(h, CID_ERR_STATE, "cid_timing_end: timing not armed");
+    int rc = CID_OK;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) rc = fail(h, CID_ERR_HIP, "cid_timing_end: stream sync failed");
+    for (int l = 0; l < NL; ++l) launch_ms_sum[l] = 0.f;
+    for (int f = 0; rc == CID_OK && f < h->tev_used; ++f)
+        for (int l = 0; l < NL; ++l) {
+            float ms = 0.f;
+            const hipEvent_t* e = h->tev.data() + (size_t)f * (NL + 1);
+            if (hipEventElapsedTime(&ms, e[l], e[l + 1]) != hipSuccess) { rc = fail(h, CID_ERR_HIP, "cid_timing_end: hipEventElapsedTime failed"); break; }
+            launch_ms_sum[l] += ms;
+        }
+    *forwards = h->tev_used;
+    for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
+    h->tev.clear();
+    h->tev_forwards = h->tev_used = 0;
+    return rc;
+}
+
+int cid_forward_timed(cid_handle_t h, const float* in, float* out, int N, int H, int W, void* ws, size_t ws_bytes,
+                      void* stream, float* launch_ms) {
+    if (!h) return CID_ERR_INVALID;
+    if (!launch_ms) return fail(h, CID_ERR_INVALID, "cid_forward_timed: null launch_ms");
+    hipEvent_t ev[NL + 1];
+    int made = 0;
+    for (; made <= NL; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) break;
+    int rc = made == NL + 1 ? CID_OK : fail(h, CID_ERR_HIP, "hipEventCreate failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rc == CID_OK) rc = run_forward(h, in, out, N, H, W, ws, ws_bytes, s, ev);
+    if (rc == CID_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(h, CID_ERR_HIP, "cid_forward_timed: stream sync failed");
+    if (rc == CID_OK)
+        for (int l = 0; l < NL; ++l)
+            if (hipEventElapsedTime(&launch_ms[l], ev[l], ev[l + 1]) != hipSuccess) rc = fail(h, CID_ERR_HIP, "hipEventElapsedTime failed");
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name : nullptr; }
+const char* cid_launch_kernel(int i) { return (i >= 0 && i < NL) ? kKernelNames[i] : nullptr; }
+
+int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes) {
+    if (i < 0 || i >= NL || !flops || !bytes) return CID_ERR_INVALID;
+    Dims d;
+    if (!make_dims(N, H, W, d)) return CID_ERR_SHAPE;
+    // output pixels (conv) / input pixels (convT) per image, as the reference evaluates each layer
+    const double s0 = (double)d.H * d.W, s1 = (double)d.H1 * d.W1, s2 = (double)d.H2 * d.W2;
+    const double su2 = (double)d.Hu2 * d.Wu2, su1 = (double)d.Hu1 * d.Wu1;
+    const double pix[NL] = {s0, s0, s1, s1, s2, s2, s2, su2, su2, su2, su1, su1};
+    const LayerDef& L = kLayers[i];
+    const double taps = L.kind == CONVT ? 4 : 9;
+    *flops = 2.0 * L.cin * L.cout * taps * pix[i] * N;
+    const double out_pix = L.kind == CONVT ? 4 * pix[i] : pix[i];
+    *bytes = 4.0 * (N * (pix[i] * L.cin + out_pix * L.cout) + (double)ref_weight_count(L) + L.cout);
+    return CID_OK;
+}
+
+}  // extern "C"

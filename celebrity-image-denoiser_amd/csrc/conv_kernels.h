@@ -1,0 +1,389 @@
+// conv_kernels.h — gfx950 (CDNA4) device kernels of the denoise forward.
+//
+// What the reference computes here: DenoiseGenerator.forward, backend/app.py:80-103 — ten 3x3
+// convolutions (+bias, +ReLU), two 2x2 max-pools, two 2x2/stride-2 transposed convolutions,
+// two channel concats and a tanh.  None of this is a translation of reference code (the
+// reference only calls torch.nn modules); it is written for the MI355X execution model:
+//
+//   * activations live in HBM as NHWC fp32, so one pixel's channels are one contiguous line;
+//   * every GEMM-shaped layer (Cin,Cout multiples of 32/64) is an implicit GEMM on the exact-f32
+//     matrix instruction v_mfma_f32_32x32x2_f32: M = 8x32 output pixels per workgroup, N = 64
+//     output channels, K walked as (32-channel chunk) x (3x3 tap) x (8-channel group);
+//   * the input halo tile (10x34 pixels x 32 channels) is staged once per chunk in LDS in 16-byte
+//     slots, pixels padded to 144 B so every ds_read_b128 of an A fragment is conflict-free;
+//   * the B (weight) fragments are pre-packed on the host in exactly the per-lane order the MFMA
+//     wants and streamed L2 -> registers as 1 KiB coalesced wave loads, one step ahead;
+//   * bias, ReLU, the 2x2 max-pool, the concat (a channel-slice store) and the transposed
+//     convolution's pixel scatter are all epilogues of the producing kernel — no pool, cat or
+//     copy kernel exists;
+//   * the 3-channel head (Cin=3, K=27) uses the same MFMA tile on a planar LDS image, and the
+//     3-channel tail (Cout=3) is a direct fp32 VALU convolution with scalar-broadcast weights.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cid {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_H = 8;    // output rows per workgroup
+constexpr int TILE_W = 32;   // output columns per workgroup (= one MFMA M dimension)
+constexpr int KCHUNK = 32;   // input channels staged in LDS per pass
+constexpr int NTILE = 64;    // output channels per workgroup
+constexpr int THREADS = 256; // 4 waves: wave w owns output rows 2w, 2w+1 of the tile
+
+struct GemmConvArgs {
+    const float* in;    // NHWC activations [N, Hin, Win, in_ps]
+    const float* w;     // packed weights (pack_gemm_weights in weights_pack.h)
+    const float* bias;  // [COUT]
+    float* out;         // MODE 0/1: [N, Hs, Ws, out_ps]; MODE 2: [N, 2*Hc, 2*Wc, out_ps]
+    float* pool;        // MODE 1: [N, Hc/2, Wc/2, COUT]
+    int N, Hin, Win, in_ps;
+    int Hc, Wc;         // region of output pixels this launch computes (<= Hin, Win)
+    int Hs, Ws;         // region stored to `out` (<= Hc, Wc) — the top-left crop of a skip tensor
+    int out_ps, out_coff;
+    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+};
+
+// 16-byte LDS slot of (tile pixel p, 4-channel group c in 0..7): pixels are padded from 8 to 9
+// slots (144 B).  A wave's ds_read_b128 of one A fragment touches 32 consecutive pixels at one c
+// per half; with a 36-dword pixel stride the 16 lanes of every ds_read_b128 service group land
+// on 16 different 4-bank columns (9p mod 16 is a bijection), i.e. conflict-free, and every
+// (tap, channel-group) address is base + immediate — no per-step address arithmetic.
+constexpr int PSLOTS = 9;
+__device__ __forceinline__ int lds_slot(int p, int c) { return p * PSLOTS + c; }
+
+// XCD-aware decode of blockIdx.x -> (M tile, N block): workgroups are dealt round-robin to the
+// 8 XCDs, so id%8 labels the XCD group; each group walks a contiguous range of tiles (whole
+// images, neighbouring halos) and the NB column blocks of one tile run back to back on it, so
+// the halo tile and the layer's weights stay in that XCD's L2.  Placement only affects speed.
+__device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd, int NB, int& mt, int& nb) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    nb = slot % NB;
+    mt = xcd * tiles_per_xcd + slot / NB;
+    return mt < tiles_total && slot / NB < tiles_per_xcd;
+}
+
+// MODE 0: 3x3 conv + bias + ReLU                      -> out (channel slice of a possibly wider buffer)
+// MODE 1: same, plus fused 2x2 max-pool                -> out (cropped region) and pool
+// MODE 2: 2x2 stride-2 transposed conv + bias (1 tap)  -> out, pixel-scattered; N index = tap*COUT + co
+template <int CIN, int COUT, int MODE>
+__global__ void __launch_bounds__(THREADS, 3) k_gemm_conv(const GemmConvArgs a) {
+    constexpr int TAPS = (MODE == 2) ? 1 : 9;
+    constexpr int HALO = (MODE == 2) ? 0 : 1;
+    constexpr int LW = TILE_W + 2 * HALO;            // LDS tile width in pixels
+    constexpr int LH = TILE_H + 2 * HALO;
+    constexpr int LPIX = LW * LH;
+    constexpr int NSLOT = LPIX * 8;                  // 16-byte slots holding data
+    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;
+    constexpr int NCHUNK = CIN / KCHUNK;
+    constexpr int NOUT = (MODE == 2) ? 4 * COUT : COUT;
+    constexpr int NB = NOUT / NTILE;
+    constexpr int SPC = TAPS * 4;                    // k-steps (8 channels each) per chunk
+    static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0, "layer dims");
+
+    __shared__ f32x4 lds[LPIX * PSLOTS];
+
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    const int tx = mt % a.tiles_x;
+    const int ty = (mt / a.tiles_x) % a.tiles_y;
+    const int n = mt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+
+    const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
+
+    // A fragment base pixel of (row 2*wave+m, column i) inside the LDS tile, tap (0,0)
+    const int pbase0 = (2 * wave) * LW + i;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w) + ((size_t)nb * NCHUNK * SPC) * 128 + lane;
+
+    f32x4 bcur[2], bnxt[2];
+    bcur[0] = wp[0];
+    bcur[1] = wp[64];
+    wp += 128;
+
+    for (int ck = 0; ck < NCHUNK; ++ck) {
+        // ---- stage the halo tile of this 32-channel chunk: global -> registers -> LDS ----
+        // (slot -> pixel/offset arithmetic is redone per chunk: a few VALU ops against ~37k MFMA
+        // cycles, and it keeps 2*NLOAD registers free for the accumulators)
+        f32x4 stage[NLOAD];
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            const int p = s >> 3, c = s & 7;
+            const int hy = p / LW, hx = p - hy * LW;
+            const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
+            const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(inb + (gy * a.Win + gx) * a.in_ps + ck * KCHUNK + c * 4);
+            stage[it] = v;
+        }
+        __syncthreads();   // every wave has finished reading the previous chunk's tile
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            if (s < NSLOT) lds[lds_slot(s >> 3, s & 7)] = stage[it];
+        }
+        __syncthreads();
+
+        f32x4 acur[2], anxt[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acur[m] = lds[lds_slot(pbase0 + m * LW, h)];
+
+#pragma unroll
+        for (int st = 0; st < SPC; ++st) {
+            const int tap = st >> 2;
+            // next step's operands: A from LDS (same chunk only), B from L2 (runs across chunks)
+            if (st + 1 < SPC) {
+                const int t2 = (st + 1) >> 2, g2 = (st + 1) & 3;
+                const int off = (TAPS == 9) ? ((t2 / 3) * LW + (t2 % 3)) : 0;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) anxt[m] = lds[lds_slot(pbase0 + m * LW + off, 2 * g2 + h)];
+            }
+            if (st + 1 < SPC || ck + 1 < NCHUNK) {
+                bnxt[0] = wp[0];
+                bnxt[1] = wp[64];
+                wp += 128;
+            }
+            (void)tap;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ns = 0; ns < 2; ++ns)
+                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bcur[ns][e], acc[m][ns], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
+            bcur[0] = bnxt[0];
+            bcur[1] = bnxt[1];
+        }
+    }
+
+    // ---- epilogue: D[row = pixel column, col = output channel]; lane holds channel j = lane&31 ----
+    // and pixel columns xo(r) = (r&3) + 8*(r>>2) + 4*h for its 16 accumulator registers r.
+    if (MODE == 2) {
+        constexpr int CB = COUT / NTILE;
+        const int tap = nb / CB, cb = nb - tap * CB;
+        const int kh = tap >> 1, kw = tap & 1;
+        const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+            const int co = cb * NTILE + ns * 32 + i;
+            const float b = a.bias[co];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int y = y0 + 2 * wave + m;
+                if (y >= a.Hc) continue;
+                float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo) * a.out_ps + a.out_coff + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (x < a.Wc) orow[(size_t)(2 * x + kw) * a.out_ps] = acc[m][ns][r] + b;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+            const int co = nb * NTILE + ns * 32 + i;
+            const float b = a.bias[co];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int y = y0 + 2 * wave + m;
+                if (y >= a.Hs) continue;
+                float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (x < a.Ws) orow[(size_t)x * a.out_ps] = fmaxf(acc[m][ns][r] + b, 0.f);
+                }
+            }
+            if (MODE == 1) {
+                // 2x2 max-pool, floor mode (nn.MaxPool2d(2,2), app.py:48,56): the four pixels of a
+                // window are registers (r, r+1) of the wave's two row tiles — no cross-lane traffic.
+                const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+                const int py = (y0 >> 1) + wave;
+                if (py < Hp) {
+                    float* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + co;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = (q & 1) * 2 + (q >> 1) * 4;
+                        const int px = (x0 >> 1) + (q & 1) + 4 * (q >> 1) + 2 * h;
+                        const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
+                        if (px < Wp) prow[(size_t)px * COUT] = fmaxf(v + b, 0.f);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head: down1[0] = Conv2d(3, 64, 3, padding=1) + ReLU  (app.py:43-44).  Reads the caller's NCHW
+// input directly (the NCHW -> NHWC change of layout is folded into this kernel), K = 27 padded
+// to 28 = 14 MFMA k-steps; memory-bound on its 64-channel NHWC output.
+struct HeadArgs {
+    const float* in;    // NCHW [N,3,H,W]
+    const float* w;     // packed [2 ns][14 steps][64 lanes]
+    const float* bias;  // [64]
+    float* out;         // NHWC [N,H,W,64]
+    int N, H, W;
+    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+};
+
+__global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
+    constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;   // 34 used columns, padded to 36
+    __shared__ float lds[3 * PLANE];
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
+    const int tx = mt % a.tiles_x;
+    const int ty = (mt / a.tiles_x) % a.tiles_y;
+    const int n = mt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+
+    for (int s = tid; s < 3 * LH * 34; s += THREADS) {
+        const int c = s / (LH * 34), rem = s - c * (LH * 34);
+        const int hy = rem / 34, hx = rem - hy * 34;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        float v = 0.f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.in[((size_t)(n * 3 + c) * a.H + gy) * a.W + gx];
+        lds[c * PLANE + hy * LW + hx] = v;
+    }
+    float bw[2][14];
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+        for (int s = 0; s < 14; ++s) bw[ns][s] = a.w[(ns * 14 + s) * 64 + lane];
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
+
+    const int pbase = (2 * wave) * LW + i;
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        // k = 2s+h flattens (ci, kh, kw) in the reference weight order [co][ci][kh][kw]; k = 27 is padding
+        const int k0 = 2 * s, k1 = (2 * s + 1 < 27) ? 2 * s + 1 : 0;
+        const int o0 = (k0 / 9) * PLANE + ((k0 % 9) / 3) * LW + (k0 % 3);
+        const int o1 = (k1 / 9) * PLANE + ((k1 % 9) / 3) * LW + (k1 % 3);
+        const int off = h ? o1 : o0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float av = lds[pbase + m * LW + off];
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns)
+                acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], acc[m][ns], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+        const int co = ns * 32 + i;
+        const float b = a.bias[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            if (y >= a.H) continue;
+            float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64 + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (x < a.W) orow[(size_t)x * 64] = fmaxf(acc[m][ns][r] + b, 0.f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail: upconv1[2] = Conv2d(64, 3, 3, padding=1) followed by torch.tanh  (app.py:77,101,103).
+// N = 3 is not a GEMM: one output pixel per lane, three fp32 accumulators, the pixel's
+// neighbourhood read from the swizzled LDS halo tile as 16-byte vectors and the weights
+// broadcast from scalar registers.  Memory-bound on its 64-channel NHWC input; writes the
+// caller's NCHW output directly (the NHWC -> NCHW change of layout is folded into this kernel).
+struct TailArgs {
+    const float* in;    // NHWC [N,H,W,64]
+    const float* w;     // packed [2 chunk][9 tap][8 group][3 co][4 ci]
+    const float* bias;  // [3]
+    float* out;         // NCHW [N,3,H,W]
+    int N, H, W;
+    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+};
+
+__global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
+    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH, NSLOT = LPIX * 8;
+    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;
+    __shared__ f32x4 lds[LPIX * PSLOTS];
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
+    const int tx = mt % a.tiles_x;
+    const int ty = (mt / a.tiles_x) % a.tiles_y;
+    const int n = mt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const int tid = threadIdx.x;
+    const int row = tid >> 5, col = tid & 31;
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    const int pb = row * LW + col;
+    for (int ck = 0; ck < 2; ++ck) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            if (s < NSLOT) {
+                const int p = s >> 3, c = s & 7;
+                const int hy = p / LW, hx = p - hy * LW;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(n * a.H + gy) * a.W + gx) * 64 + ck * KCHUNK + c * 4);
+                lds[lds_slot(p, c)] = v;
+            }
+        }
+        __syncthreads();
+        const float* wk = a.w + ck * (9 * 8 * 12);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int p = pb + (tap / 3) * LW + (tap % 3);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 x = lds[lds_slot(p, g)];
+                const float* wv = wk + (tap * 8 + g) * 12;   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = fmaf(x[e], wv[e], acc0);
+                    acc1 = fmaf(x[e], wv[4 + e], acc1);
+                    acc2 = fmaf(x[e], wv[8 + e], acc2);
+                }
+            }
+        }
+    }
+    const int y = y0 + row, x = x0 + col;
+    if (y < a.H && x < a.W) {
+        const size_t plane = (size_t)a.H * a.W;
+        float* o = a.out + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+        o[0] = tanhf(acc0 + a.bias[0]);
+        o[plane] = tanhf(acc1 + a.bias[1]);
+        o[2 * plane] = tanhf(acc2 + a.bias[2]);
+    }
+}
+
+}  // namespace cid

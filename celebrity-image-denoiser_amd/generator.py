@@ -1,0 +1,210 @@
+"""`DenoiseGenerator`: the reference's nn.Module surface over the HIP forward.
+
+The reference's boundary for this path is the torch.nn.Module protocol on the object stored in
+`PT_MODELS["denoise"]` (reference backend/app.py:319-320); its callers use exactly
+    DenoiseGenerator()                          app.py:320, denoisegan_eval.py:67
+    .to(device)                                 app.py:320
+    .load_state_dict(sd, strict=False|True)     app.py:272, denoisegan_eval.py:69
+    .eval() -> self                             app.py:273,423
+    __call__(x)                                 app.py:433, denoise_eavl_iter.py:96
+    .state_dict()                               training.py:361
+This class offers the same calls with the same parameter names, shapes and default
+initialisation (the submodules below are parameter containers built from stock nn layers, so
+key names, `.to()`, `state_dict()` and `load_state_dict()` behave as in the reference), but
+`forward` never touches ATen compute: it hands raw device pointers to `cid_forward`
+(include/cid.h), which runs the hand-written gfx950 kernels.  There is no CPU path — a CPU
+tensor or a missing libcid.so raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _block(cin, cmid, cout, last_relu=True):
+    layers = [nn.Conv2d(cin, cmid, kernel_size=3, padding=1), nn.ReLU(), nn.Conv2d(cmid, cout, kernel_size=3, padding=1)]
+    if last_relu:
+        layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class DenoiseGenerator(nn.Module):
+    """Two-level U-Net denoiser; parameters as in reference backend/app.py:39-78."""
+
+    def __init__(self):
+        super().__init__()
+        # parameter containers only — indices 0 and 2 of each Sequential hold the convs, as in the reference
+        self.down1 = _block(3, 64, 64)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.down2 = _block(64, 128, 128)
+        self.pool2 = nn.MaxPool2d(2, 2)
+        self.bottleneck = _block(128, 256, 256)
+        self.up2 = nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2)
+        self.upconv2 = _block(256, 128, 128)
+        self.up1 = nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2)
+        self.upconv1 = _block(128, 64, 3, last_relu=False)
+        self._cid = ctypes.c_void_p()
+        _lib.check(None, _lib.lib().cid_create(ctypes.byref(self._cid)))
+        self._blob = None          # packed weights on the device (torch uint8 tensor, owns the memory)
+        self._packed_sig = None    # signature of the parameters the blob was packed from
+        self._ws = None            # activation arena (torch uint8 tensor, grow-only)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_cid", None):
+                _lib.lib().cid_destroy(self._cid)
+                self._cid = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _signature(self):
+        return tuple((k, p.data_ptr(), p._version, str(p.device)) for k, p in self.named_parameters())
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _stage_parameters(self) -> None:
+        L = _lib.lib()
+        for key, p in self.named_parameters():
+            a = np.ascontiguousarray(p.detach().to("cpu", torch.float32).numpy())
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            _lib.check(self._cid, L.cid_set_weight(self._cid, key.encode(), a.ctypes.data, shape, a.ndim))
+
+    def pack_weights_host(self) -> torch.Tensor:
+        """The packed weights blob as a host uint8 tensor (what `pack_weights` uploads): lets a
+        transport that is not RCCL (gloo in the CPU tests) move the same bytes."""
+        L = _lib.lib()
+        self._stage_parameters()
+        out = np.empty(L.cid_packed_weights_bytes(), dtype=np.uint8)
+        _lib.check(self._cid, L.cid_export_packed(self._cid, out.ctypes.data, out.nbytes))
+        return torch.from_numpy(out)
+
+    def pack_weights(self, force: bool = False) -> torch.Tensor:
+        """Repack the 24 parameter tensors into the kernels' layout on the module's GPU (if they
+        changed since the last call) and return the packed device blob."""
+        sig = self._signature()
+        if not force and self._blob is not None and sig == self._packed_sig:
+            return self._blob
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "DenoiseGenerator runs only on an AMD GPU (HIP kernels behind libcid.so); move it with "
+                ".to('cuda') first. There is no CPU fallback."
+            )
+        L = _lib.lib()
+        self._stage_parameters()
+        blob = torch.empty(L.cid_packed_weights_bytes(), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self._cid, L.cid_upload_weights(self._cid, blob.data_ptr(), stream))
+        self._blob, self._packed_sig = blob, sig
+        return blob
+
+    def adopt_packed_weights(self, blob: torch.Tensor, update_parameters: bool = True) -> None:
+        """Use a packed device blob produced elsewhere (another rank's `pack_weights()`, received
+        by RCCL broadcast).  With update_parameters the nn.Parameters are refreshed from it so
+        `state_dict()` agrees with what the kernels compute."""
+        L = _lib.lib()
+        if blob.dtype != torch.uint8 or blob.numel() != L.cid_packed_weights_bytes() or not blob.is_contiguous():
+            raise ValueError("adopt_packed_weights: expected a contiguous uint8 tensor of cid_packed_weights_bytes()")
+        if blob.device.type == "cuda":
+            if self._device() != blob.device:
+                self.to(blob.device)
+            _lib.check(self._cid, L.cid_attach_weights(self._cid, blob.data_ptr()))
+            self._blob = blob
+        else:
+            update_parameters = True   # a host blob can only refresh the parameters; packing happens on .to('cuda')
+        if update_parameters:
+            host = blob.cpu().numpy()
+            _lib.check(self._cid, L.cid_import_packed(self._cid, host.ctypes.data, host.nbytes))
+            with torch.no_grad():
+                for key, p in self.named_parameters():
+                    a = np.empty(tuple(p.shape), dtype=np.float32)
+                    _lib.check(self._cid, L.cid_get_weight(self._cid, key.encode(), a.ctypes.data, a.size))
+                    p.copy_(torch.from_numpy(a))
+        self._packed_sig = self._signature() if blob.device.type == "cuda" else None
+
+    # ------------------------------------------------------------------ forward
+    def _prepare(self, x: torch.Tensor):
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("DenoiseGenerator expects a torch.Tensor [N,3,H,W]")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"expected input of shape [N,3,H,W], got {list(x.shape)}")
+        if x.device.type != "cuda":
+            raise RuntimeError(
+                "DenoiseGenerator.forward got a CPU tensor: this implementation is GPU-only (hand-written HIP "
+                "kernels); there is no CPU fallback. Move the input with .to('cuda')."
+            )
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 input (the reference computes in fp32), got {x.dtype}")
+        if x.device != self._device():
+            raise RuntimeError(f"input on {x.device} but module parameters on {self._device()}")
+        n, _, h, w = x.shape
+        if n < 1:
+            raise RuntimeError("empty batch")
+        L = _lib.lib()
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        if L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) != _lib.CID_OK:
+            # the reference fails here too (ATen: "Output size is too small")
+            raise RuntimeError(f"Given input size: ({h}x{w}). Calculated output size is too small (H and W must be >= 4)")
+        self.pack_weights()
+        need = ctypes.c_size_t()
+        _lib.check(self._cid, L.cid_workspace_bytes(n, h, w, ctypes.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        x = x.contiguous()
+        y = torch.empty((n, 3, ho.value, wo.value), dtype=torch.float32, device=x.device)
+        return x, y, n, h, w
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[N,3,H,W] fp32 in [-1,1] on the GPU -> [N,3,4*(H//4),4*(W//4)] fp32 in (-1,1).
+        Same contract as the reference forward (app.py:80-103); asynchronous on the current stream."""
+        x, y, n, h, w = self._prepare(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._cid, _lib.lib().cid_forward(self._cid, x.data_ptr(), y.data_ptr(), n, h, w,
+                                                         self._ws.data_ptr(), self._ws.numel(), stream))
+        return y
+
+    def forward_timed(self, x: torch.Tensor):
+        """forward + per-launch milliseconds from HIP events on the launch stream (measurement aid)."""
+        x, y, n, h, w = self._prepare(x)
+        ms = (ctypes.c_float * _lib.CID_NUM_LAUNCHES)()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._cid, _lib.lib().cid_forward_timed(self._cid, x.data_ptr(), y.data_ptr(), n, h, w,
+                                                               self._ws.data_ptr(), self._ws.numel(), stream, ms))
+        return y, list(ms)
+
+
+    def timing_begin(self, max_forwards: int) -> None:
+        """Arm per-launch HIP-event timing for the next `max_forwards` forwards (no per-forward sync)."""
+        _lib.check(self._cid, _lib.lib().cid_timing_begin(self._cid, int(max_forwards)))
+
+    def timing_end(self):
+        """-> (per-launch milliseconds summed over the recorded forwards, number of forwards)."""
+        ms = (ctypes.c_float * _lib.CID_NUM_LAUNCHES)()
+        n = ctypes.c_int()
+        dev = self._device()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self._cid, _lib.lib().cid_timing_end(self._cid, stream, ms, ctypes.byref(n)))
+        return list(ms), n.value
+
+
+def launch_table(n: int, h: int, w: int):
+    """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes)] of one forward."""
+    L = _lib.lib()
+    rows = []
+    for i in range(_lib.CID_NUM_LAUNCHES):
+        f, b = ctypes.c_double(), ctypes.c_double()
+        _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f), ctypes.byref(b)))
+        rows.append((L.cid_launch_name(i).decode(), L.cid_launch_kernel(i).decode(), f.value, b.value))
+    return rows

@@ -1,0 +1,142 @@
+/*
+ * cid.h — C ABI of the MI355X-native denoise forward ("cid" = celebrity image denoiser).
+ *
+ * The reference has no FFI: its boundary for this path is the torch.nn.Module protocol on the
+ * object stored in PT_MODELS["denoise"] (reference backend/app.py:319-320).  Each entry point
+ * below names the reference interface it stands in for.  All pointers are plain host or device
+ * addresses; no torch types cross this boundary.  Device memory (weights blob, workspace, input,
+ * output) is owned by the caller — in the Python host layer that is PyTorch-ROCm's allocator.
+ *
+ * Threading: a handle is not re-entrant — one forward in flight per handle, matching the
+ * reference's single-threaded use (backend/app.py:358-359,433).
+ * Errors: every function returns CID_OK (0) or a CID_ERR_* code; cid_last_error(h) holds the text.
+ */
+#ifndef CID_H_
+#define CID_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cid_handle_s* cid_handle_t;
+
+enum {
+    CID_OK = 0,
+    CID_ERR_INVALID = 1,   /* null pointer / bad argument                                   */
+    CID_ERR_SHAPE = 2,     /* tensor shape not accepted (e.g. H or W < 4, wrong weight dims) */
+    CID_ERR_KEY = 3,       /* unknown state_dict key                                        */
+    CID_ERR_STATE = 4,     /* call out of order (forward before weights attached, ...)      */
+    CID_ERR_WORKSPACE = 5, /* workspace too small or misaligned                             */
+    CID_ERR_HIP = 6        /* a HIP runtime call or kernel launch failed                    */
+};
+
+/* Number of parameter tensors (24) and scalars (1,827,587) of the module.
+ * reference: DenoiseGenerator.__init__, backend/app.py:39-78. */
+#define CID_NUM_PARAMS 24
+#define CID_NUM_PARAM_ELEMS 1827587
+
+/* Kernel launches of one forward, in order (names: cid_launch_name). */
+#define CID_NUM_LAUNCHES 12
+
+const char* cid_version(void);
+
+/* DenoiseGenerator()  — backend/app.py:320 (constructor; here: host-side state only). */
+int cid_create(cid_handle_t* out);
+/* garbage collection of the module. */
+void cid_destroy(cid_handle_t h);
+/* Python exception text — the reference raises; this ABI returns codes + this string. */
+const char* cid_last_error(cid_handle_t h);
+
+/*
+ * Module.load_state_dict, one tensor at a time — backend/app.py:272 (via load_state_safely,
+ * :257-274).  `key` is a reference state_dict key ("down1.0.weight", "up2.bias", ...; any
+ * "module." prefix already stripped by the caller), `host_data` fp32 in the reference layout
+ * (Conv2d [Cout,Cin,3,3], ConvTranspose2d [Cin,Cout,2,2], bias [Cout]), `shape`/`ndim` its
+ * dims.  The tensor is repacked into the kernels' layout inside the handle's host staging blob.
+ * Unknown key -> CID_ERR_KEY; wrong shape -> CID_ERR_SHAPE (the reference's size-mismatch error).
+ */
+int cid_set_weight(cid_handle_t h, const char* key, const float* host_data, const int64_t* shape, int ndim);
+
+/* Module.state_dict()[key] — backend/trainingcode/denoise_gan_code/training.py:361.
+ * Unpacks the staged tensor back into reference layout (`host_out` holds `count` floats). */
+int cid_get_weight(cid_handle_t h, const char* key, float* host_out, size_t count);
+
+/* How many of the 24 tensors have not been set since cid_create (strict=True check). */
+int cid_missing_weights(cid_handle_t h, int* missing);
+
+/* i-th state_dict key in reference order, NULL if i is out of range. */
+const char* cid_param_key(int i);
+
+/* Size in bytes of the packed device weights blob (the unit the multi-GPU path broadcasts). */
+size_t cid_packed_weights_bytes(void);
+
+/*
+ * Module.to(device) for the parameters — backend/app.py:320.  Copies the packed staging blob
+ * to `device_blob` (caller-owned, >= cid_packed_weights_bytes(), 256-byte aligned) on `stream`
+ * (hipStream_t, may be NULL) and attaches it.
+ */
+int cid_upload_weights(cid_handle_t h, void* device_blob, void* stream);
+
+/* Copy the packed host staging blob out (`bytes` must equal cid_packed_weights_bytes()): the
+ * exact bytes cid_upload_weights sends to the device, for transports that move it themselves. */
+int cid_export_packed(cid_handle_t h, void* host_out, size_t bytes);
+/* Replace the host staging blob with packed bytes produced by another handle's
+ * cid_export_packed / device blob; afterwards all 24 tensors count as set and cid_get_weight
+ * returns them in reference layout. */
+int cid_import_packed(cid_handle_t h, const void* host_in, size_t bytes);
+
+/* Adopt a device blob that already holds packed weights (e.g. filled by an RCCL broadcast from
+ * the rank that ran cid_upload_weights).  No copy. */
+int cid_attach_weights(cid_handle_t h, const void* device_blob);
+
+/* Output spatial size of the forward: Ho = 4*floor(H/4), Wo = 4*floor(W/4) (two floor-mode
+ * 2x2 pools, two x2 transposed convs, skip tensors cropped top-left) — backend/app.py:80-103.
+ * H or W < 4 -> CID_ERR_SHAPE (the reference raises "Output size is too small"). */
+int cid_out_shape(int H, int W, int* Ho, int* Wo);
+
+/* Bytes of scratch device memory one forward of [N,3,H,W] needs (activation arena, NHWC fp32). */
+int cid_workspace_bytes(int N, int H, int W, size_t* bytes);
+
+/*
+ * Module.__call__(x) / forward — backend/app.py:433 (net(x_pt)), :80-103.
+ * in_nchw : device, fp32, contiguous [N,3,H,W], values nominally in [-1,1]  (app.py:401-406)
+ * out_nchw: device, fp32, contiguous [N,3,Ho,Wo], tanh range                (app.py:103)
+ * workspace: device scratch, 256-byte aligned, >= cid_workspace_bytes(N,H,W)
+ * stream  : hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
+ */
+int cid_forward(cid_handle_t h, const float* in_nchw, float* out_nchw, int N, int H, int W,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Same forward, with a HIP event recorded on `stream` around every kernel launch; synchronises
+ * the stream and writes the CID_NUM_LAUNCHES per-launch durations in milliseconds to launch_ms.
+ * Measurement aid for bench.py's roofline object; not part of the reference surface.
+ */
+int cid_forward_timed(cid_handle_t h, const float* in_nchw, float* out_nchw, int N, int H, int W,
+                      void* workspace, size_t workspace_bytes, void* stream, float* launch_ms);
+
+/*
+ * Per-launch timing across many forwards without a host sync per forward (bench.py's timed
+ * region).  cid_timing_begin arms the handle: each of the next `max_forwards` cid_forward calls
+ * records CID_NUM_LAUNCHES+1 HIP events on its stream.  cid_timing_end synchronises `stream`,
+ * writes the per-launch durations summed over the recorded forwards (milliseconds) to
+ * launch_ms_sum[CID_NUM_LAUNCHES] and the number of forwards to *forwards, and disarms.
+ */
+int cid_timing_begin(cid_handle_t h, int max_forwards);
+int cid_timing_end(cid_handle_t h, void* stream, float* launch_ms_sum, int* forwards);
+
+/* Name of the i-th launch ("down1.0", ..., "upconv1.2"), the reference layer(s) it computes. */
+const char* cid_launch_name(int i);
+/* Device kernel symbol substring of the i-th launch (to match rocprofv3 kernel-trace rows). */
+const char* cid_launch_kernel(int i);
+/* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
+ * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
+int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CID_H_ */

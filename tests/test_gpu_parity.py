@@ -1,0 +1,179 @@
+"""GPU parity: the HIP forward, called through the C ABI (via the Python host class), against
+  (1) the golden fixtures recorded from the reference class itself, and
+  (2) the CPU oracles (ATen restatement = the reference's arithmetic provider; C restatement).
+
+Stated fp32 tolerances (BASELINE.md section 4 / SURVEY 8d):
+    per-pixel  max|y_hip - y_ref| <= 1e-5      on the tanh output
+    per-stage  max|delta|         <= 1e-5 * max(1, max|stage|)
+    PSNR_delta = |PSNR(y_hip, clean) - PSNR(y_ref, clean)| <= 0.01 dB
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from celebrity_image_denoiser_amd import synth  # noqa: E402
+
+TOL = 1e-5
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
+
+
+@pytest.fixture(scope="module")
+def models(weight_sets):
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    return {k: cid.load(v, device="cuda:0", strict=True) for k, v in weight_sets.items()}
+
+
+def _run(model, x):
+    y = model(torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0"))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(
+    os.path.join(os.path.dirname(__file__), "golden", "tiny_*.npz"))))
+def test_golden_tiny(models, golden_dir, name):
+    """16x16, 20x24 (ragged tiles), 13x18 / 7x9 (crop path: output 12x16 / 4x8), 4x4 (minimum)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    y = _run(models[name.split("_")[1]], g["x"])
+    assert y.shape == g["out"].shape
+    assert np.abs(y - g["out"]).max() <= TOL
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_golden_128(models, golden_dir, weight_sets, wset):
+    from celebrity_image_denoiser_amd import psnr
+
+    g = np.load(os.path.join(golden_dir, f"full_{wset}_128.npz"))
+    x, clean, _ = synth.make_batch(2, 128, 128, 100)
+    y = _run(models[wset], x)
+    assert np.abs(y - g["out"]).max() <= TOL
+    assert abs(psnr(y, clean) - psnr(g["out"], clean)) <= 0.01
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+@pytest.mark.parametrize("case", ["n4_128", "n1_256"])
+def test_golden_stats(models, golden_dir, wset, case):
+    """Output moments / sampled pixels / PSNR of the reference at N=4 128x128 and N=1 256x256."""
+    from celebrity_image_denoiser_amd import psnr
+
+    st = json.load(open(os.path.join(golden_dir, "stats.json")))[f"{wset}_{case}"]
+    x, clean, _ = synth.make_batch(st["n"], st["h"], st["w"], st["first_index"])
+    y = _run(models[wset], x)
+    g = st["stages"]["out"]
+    assert list(y.shape) == g["shape"]
+    assert np.abs(y.reshape(-1)[g["idx"]] - np.array(g["samples"])).max() <= TOL
+    assert abs(float(y.astype(np.float64).sum()) - g["sum"]) <= 1e-5 * y.size
+    assert abs(psnr(y, clean) - st["psnr_out_vs_clean"]) <= 0.01
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+@pytest.mark.parametrize("shape", [(3, 40, 72), (1, 64, 64), (5, 36, 100), (2, 9, 4)])
+def test_against_cpu_oracles(models, weight_sets, wset, shape):
+    """Seeded inputs at sizes the oracles finish in seconds, incl. multi-tile and ragged shapes."""
+    from oracle import c_oracle, torch_oracle
+
+    n, h, w = shape
+    x, _, _ = synth.make_batch(n, h, w, first_index=500)
+    y = _run(models[wset], x)
+    ref_t = torch_oracle.forward(weight_sets[wset], x).numpy()
+    ref_c = c_oracle.forward(weight_sets[wset], x)
+    assert y.shape == ref_t.shape
+    assert np.abs(y - ref_t).max() <= TOL
+    assert np.abs(y - ref_c).max() <= TOL
+
+
+def test_closer_to_exact_than_tolerance(models, weight_sets):
+    """Against the all-float64 forward the HIP result must be as accurate as the fp32 reference is
+    (both are fp32 evaluations of the same real-valued function)."""
+    from oracle import torch_oracle
+
+    x, _, _ = synth.make_batch(2, 64, 64, first_index=700)
+    exact = torch_oracle.forward(weight_sets["hot"], x, dtype=torch.float64).numpy()
+    ref32 = torch_oracle.forward(weight_sets["hot"], x).numpy()
+    y = _run(models["hot"], x)
+    e_hip, e_ref = np.abs(y - exact).max(), np.abs(ref32 - exact).max()
+    assert e_hip <= max(4 * e_ref, 2e-6)
+
+
+def test_batch_independence_full_size(models):
+    """Size-independent property at BASELINE config-2 image size: every image of a batch of 24
+    equals the same image run alone, bit for bit (the kernels have no cross-sample term)."""
+    x, _, _ = synth.make_batch(24, 128, 128, first_index=1000)
+    yb = _run(models["hot"], x)
+    for i in (0, 7, 23):
+        assert np.array_equal(yb[i:i + 1], _run(models["hot"], x[i:i + 1]))
+
+
+def test_deterministic(models):
+    x, _, _ = synth.make_batch(8, 128, 128, first_index=1100)
+    assert np.array_equal(_run(models["default"], x), _run(models["default"], x))
+
+
+def test_zero_weights_give_tanh_bias(models):
+    """Algebraic property: with all conv weights zero the output is tanh(bias of the last conv)."""
+    import celebrity_image_denoiser_amd as cid
+
+    sd = {k: np.zeros_like(v) for k, v in synth.make_state_dict("default").items()}
+    sd["upconv1.2.bias"] = np.array([0.25, -0.5, 1.5], np.float32)
+    m = cid.load(sd, device="cuda:0", strict=True)
+    y = _run(m, synth.make_batch(1, 16, 24)[0])
+    for c in range(3):
+        assert np.allclose(y[0, c], np.tanh(sd["upconv1.2.bias"][c]), atol=1e-6)
+
+
+def test_errors_are_loud(models):
+    m = models["default"]
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 8, 8))                      # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 3, 3, device="cuda:0"))     # too small, like the reference
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 8, 8, device="cuda:0", dtype=torch.float16))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 8, 8, device="cuda:0"))
+
+
+def test_state_dict_reload_repacks(models, weight_sets):
+    """load_state_dict on a live module takes effect on the next forward (weights repacked)."""
+    import celebrity_image_denoiser_amd as cid
+
+    x, _, _ = synth.make_batch(1, 16, 16)
+    m = cid.load(weight_sets["default"], device="cuda:0")
+    y0 = _run(m, x)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}, strict=True)
+    y1 = _run(m, x)
+    assert np.array_equal(y1, _run(models["hot"], x)) and not np.array_equal(y0, y1)
+
+
+def test_iterated_denoise_and_host_roundtrip(models):
+    import celebrity_image_denoiser_amd as cid
+
+    x = torch.from_numpy(synth.make_batch(3, 32, 32)[0])
+    y3 = cid.denoise(models["hot"], x, iterations=3)
+    assert y3.device.type == "cpu" and y3.shape == x.shape
+    z = x.to("cuda:0")
+    for _ in range(3):
+        z = models["hot"](z)
+    assert torch.equal(y3, z.cpu())
+    y_split = cid.denoise(models["hot"], x, max_batch=2)
+    assert torch.equal(y_split, cid.denoise(models["hot"], x))
+
+
+def test_native_library_is_loaded(models):
+    """The parity above ran through libcid.so, not through any PyTorch op."""
+    from celebrity_image_denoiser_amd import _lib
+
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(_lib.LIB_PATH) in maps
