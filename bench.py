@@ -40,12 +40,24 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-le
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 GB/s achievable
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(sd, budget_s: float = 15.0):
     """Time the CPU oracle (kind "port": the reference forward re-stated on ATen CPU ops) on a bounded
     sample of the same workload: batches of 32 images 128x128 until ~budget_s of CPU work."""
     from oracle import torch_oracle
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     x, _, _ = synth.make_batch(32, 128, 128, first_index=5000)
     torch_oracle.forward(sd, x[:4])   # warm-up (oneDNN primitive creation)
@@ -62,6 +74,7 @@ def cpu_baseline(sd, budget_s: float = 15.0):
     try:   # second opinion: the dependency-free C restatement (OpenMP), 8 images
         from oracle import c_oracle
 
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
         t0 = time.perf_counter()
         c_oracle.forward(sd, x[:8])
         out["c_oracle_images_per_sec"] = round(8 / (time.perf_counter() - t0), 2)

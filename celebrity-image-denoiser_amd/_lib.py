@@ -60,6 +60,14 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: the HIP extension is not built. This package has no CPU or PyTorch "
                 "fallback; build it with `make -C celebrity-image-denoiser_amd/csrc` (needs hipcc)."
             )
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (same SONAME as
+        # /opt/rocm's).  Load torch's copy first so libcid.so binds to the runtime that owns the
+        # tensors and streams it is handed; two runtimes in one process do not see each other's devices.
+        import torch
+
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError here = header and library out of sync
