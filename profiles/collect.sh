@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the MI355X box from the repo root:  bash profiles/collect.sh <tag>
+# Writes raw rocprofv3 CSVs under gpurun_out/prof_<tag>/{stats,pmc_sq,pmc_fetch,pmc_write}; summarise with
+# profiles/summarize.py.  Counter passes are separate runs with --kernel-trace only (never combined
+# with other trace domains), as the MI355X guide prescribes.
+set -o pipefail
+TAG=${1:-run}
+OUT=gpurun_out/prof_${TAG}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || { echo "stats pass failed"; tail -5 "$OUT/stats.err"; exit 1; }
+echo "stats pass done"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_sq" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $SHORT > "$OUT/bench_pmc_sq.json" 2> "$OUT/pmc_sq.err" || { echo "pmc sq pass failed"; tail -5 "$OUT/pmc_sq.err"; exit 1; }
+echo "pmc sq pass done"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_fetch" --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- $SHORT > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { echo "pmc fetch pass failed"; tail -5 "$OUT/pmc_fetch.err"; exit 1; }
+echo "pmc fetch pass done"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_write" --pmc WRITE_SIZE -- $SHORT > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" || { echo "pmc write pass failed"; tail -5 "$OUT/pmc_write.err"; exit 1; }
+echo "pmc write pass done"
+find "$OUT" -name "*.csv" | head -40
