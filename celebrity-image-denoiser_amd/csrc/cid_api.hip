@@ -24,9 +24,9 @@ const LayerDef kLayers[NL] = {
     {"up1", CONVT, 128, 64},         {"upconv1.0", CONV, 128, 64},     {"upconv1.2", TAIL, 64, 3},
 };
 const char* kKernelNames[NL] = {
-    "k_conv_head", "k_gemm_conv<64, 64, 1>", "k_gemm_conv<64, 128, 0>", "k_gemm_conv<128, 128, 1>",
-    "k_gemm_conv<128, 256, 0>", "k_gemm_conv<256, 256, 0>", "k_gemm_conv<256, 128, 2>", "k_gemm_conv<256, 128, 0>",
-    "k_gemm_conv<128, 128, 0>", "k_gemm_conv<128, 64, 2>", "k_gemm_conv<128, 64, 0>", "k_conv_tail",
+    "k_conv_head", "k_gemm_conv<64, 64, 1,", "k_gemm_conv<64, 128, 0,", "k_gemm_conv<128, 128, 1,",
+    "k_gemm_conv<128, 256, 0,", "k_gemm_conv<256, 256, 0,", "k_gemm_conv<256, 128, 2,", "k_gemm_conv<256, 128, 0,",
+    "k_gemm_conv<128, 128, 0,", "k_gemm_conv<128, 64, 2,", "k_gemm_conv<128, 64, 0,", "k_conv_tail",
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -21,6 +21,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace cid {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,8 +70,22 @@ __device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd,
 // MODE 0: 3x3 conv + bias + ReLU                      -> out (channel slice of a possibly wider buffer)
 // MODE 1: same, plus fused 2x2 max-pool                -> out (cropped region) and pool
 // MODE 2: 2x2 stride-2 transposed conv + bias (1 tap)  -> out, pixel-scattered; N index = tap*COUT + co
-template <int CIN, int COUT, int MODE>
-__global__ void __launch_bounds__(THREADS, 3) k_gemm_conv(const GemmConvArgs a) {
+//
+// Pipeline of one workgroup (4 waves, 2 workgroups per CU):
+//   prologue : bias -> registers; halo tile of chunk 0 -> LDS; B fragments of steps 0,1 -> registers
+//   chunk ck : 36 steps of {A(st+1) <- LDS, B(st+2) <- L2, one 16-byte piece of chunk ck+1's halo
+//              tile <- HBM/L2 into a register, 16 MFMAs}.  All loads fly under the MFMAs; vmcnt is
+//              in-order, so the one-per-step spread of the halo loads keeps each B wait short.
+//   seam     : barrier, 11 ds_write_b128 (prefetched tile -> LDS), barrier.
+//   epilogue : bias/ReLU/pool/scatter straight from the accumulators (bias was loaded in the
+//              prologue: a load left pending here makes hipcc wait vmcnt(0) before every guarded
+//              store, and since CDNA4's vmcnt counts stores too that serialises the whole tail).
+//
+// ABLATE (timing experiments only, csrc/tools/layer_bench.hip; results are wrong when non-zero):
+//   bit 0: no halo prefetch/restage after chunk 0   bit 1: B fragments loaded once
+//   bit 2: A fragments read once per chunk          bit 3: no epilogue stores
+template <int CIN, int COUT, int MODE, int ABLATE = 0, int WPS = 2>
+__global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a) {
     constexpr int TAPS = (MODE == 2) ? 1 : 9;
     constexpr int HALO = (MODE == 2) ? 0 : 1;
     constexpr int LW = TILE_W + 2 * HALO;            // LDS tile width in pixels
@@ -81,7 +97,9 @@ __global__ void __launch_bounds__(THREADS, 3) k_gemm_conv(const GemmConvArgs a) 
     constexpr int NOUT = (MODE == 2) ? 4 * COUT : COUT;
     constexpr int NB = NOUT / NTILE;
     constexpr int SPC = TAPS * 4;                    // k-steps (8 channels each) per chunk
-    static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0, "layer dims");
+    constexpr int NBUF = (SPC % 3 == 0) ? 3 : 2;     // B register ring; prefetch distance NBUF-1 steps
+    constexpr int DIST = NBUF - 1;
+    static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0 && SPC % NBUF == 0, "layer dims");
 
     __shared__ f32x4 lds[LPIX * PSLOTS];
 
@@ -96,7 +114,36 @@ __global__ void __launch_bounds__(THREADS, 3) k_gemm_conv(const GemmConvArgs a) 
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
 
+    // output-channel block of this workgroup (MODE 2: nb also selects the (kh,kw) tap)
+    constexpr int CB = COUT / NTILE;
+    const int tap2 = (MODE == 2) ? nb / CB : 0;
+    const int cobase = ((MODE == 2) ? (nb - tap2 * CB) : nb) * NTILE;
+    float bias_v[2];
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
+
+    // ---- this thread's pieces of the halo tile: piece `it` is LDS slot s = it*256 + tid ----
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
+    int goff[NLOAD];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+        const int s = it * THREADS + tid;
+        const int p = s >> 3, c = s & 7;
+        const int hy = p / LW, hx = p - hy * LW;
+        const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
+        const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        goff[it] = ok ? ((gy * a.Win + gx) * a.in_ps + c * 4) : 0;   // !ok: any valid address, value discarded
+        okmask |= (ok ? 1u : 0u) << it;
+    }
+    const int wslot = lds_slot(tid >> 3, tid & 7);   // slot of piece 0; piece `it` is wslot + it*32*PSLOTS
+    auto halo_load = [&](int it, int ck) -> f32x4 {   // raw load; the padding mask is applied at store time
+        return *reinterpret_cast<const f32x4*>(inb + goff[it] + ck * KCHUNK);
+    };
+    auto halo_store = [&](int it, f32x4 v) {
+        if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the convolution
+        if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[wslot + it * (THREADS / 8) * PSLOTS] = v;
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -110,124 +157,148 @@ __global__ void __launch_bounds__(THREADS, 3) k_gemm_conv(const GemmConvArgs a) 
     const int pbase0 = (2 * wave) * LW + i;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.w) + ((size_t)nb * NCHUNK * SPC) * 128 + lane;
 
-    f32x4 bcur[2], bnxt[2];
-    bcur[0] = wp[0];
-    bcur[1] = wp[64];
-    wp += 128;
-
-    for (int ck = 0; ck < NCHUNK; ++ck) {
-        // ---- stage the halo tile of this 32-channel chunk: global -> registers -> LDS ----
-        // (slot -> pixel/offset arithmetic is redone per chunk: a few VALU ops against ~37k MFMA
-        // cycles, and it keeps 2*NLOAD registers free for the accumulators)
-        f32x4 stage[NLOAD];
+    f32x4 pre[NLOAD];
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it) {
-            const int s = it * THREADS + tid;
-            const int p = s >> 3, c = s & 7;
-            const int hy = p / LW, hx = p - hy * LW;
-            const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-            const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(inb + (gy * a.Win + gx) * a.in_ps + ck * KCHUNK + c * 4);
-            stage[it] = v;
-        }
-        __syncthreads();   // every wave has finished reading the previous chunk's tile
+    for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
+    f32x4 bq[NBUF][2];
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it) {
-            const int s = it * THREADS + tid;
-            if (s < NSLOT) lds[lds_slot(s >> 3, s & 7)] = stage[it];
-        }
-        __syncthreads();
+    for (int d = 0; d < DIST; ++d) {
+        bq[d][0] = wp[0];
+        bq[d][1] = wp[64];
+        wp += 128;
+    }
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+    __syncthreads();
 
+    auto chunk = [&](auto pref_tag, int ck) {
+        constexpr bool PREF = decltype(pref_tag)::value && !(ABLATE & 1);   // another chunk follows
         f32x4 acur[2], anxt[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) acur[m] = lds[lds_slot(pbase0 + m * LW, h)];
-
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
-            const int tap = st >> 2;
-            // next step's operands: A from LDS (same chunk only), B from L2 (runs across chunks)
-            if (st + 1 < SPC) {
+            if (st + 1 < SPC && !(ABLATE & 4)) {
                 const int t2 = (st + 1) >> 2, g2 = (st + 1) & 3;
                 const int off = (TAPS == 9) ? ((t2 / 3) * LW + (t2 % 3)) : 0;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) anxt[m] = lds[lds_slot(pbase0 + m * LW + off, 2 * g2 + h)];
             }
-            if (st + 1 < SPC || ck + 1 < NCHUNK) {
-                bnxt[0] = wp[0];
-                bnxt[1] = wp[64];
+            if ((decltype(pref_tag)::value || st + DIST < SPC) && !(ABLATE & 2)) {
+                bq[(st + DIST) % NBUF][0] = wp[0];
+                bq[(st + DIST) % NBUF][1] = wp[64];
                 wp += 128;
             }
-            (void)tap;
+            if (PREF && st < NLOAD) pre[st] = halo_load(st, ck + 1);
+            constexpr int BSEL = (ABLATE & 2) ? 0 : -1;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int ns = 0; ns < 2; ++ns)
-                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bcur[ns][e], acc[m][ns], 0, 0, 0);
+                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bq[BSEL < 0 ? st % NBUF : 0][ns][e], acc[m][ns], 0, 0, 0);
+            if (st + 1 < SPC && !(ABLATE & 4)) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
-            bcur[0] = bnxt[0];
-            bcur[1] = bnxt[1];
+                for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // loads of step st stay ahead of step st+1's MFMAs
         }
+        if (PREF) {
+            if (SPC < NLOAD) {
+#pragma unroll
+                for (int it = SPC; it < NLOAD; ++it) pre[it] = halo_load(it, ck + 1);
+            }
+            __syncthreads();   // every wave has finished reading this chunk's tile
+#pragma unroll
+            for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+            __syncthreads();
+        }
+    };
+    for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
+    chunk(std::false_type{}, NCHUNK - 1);
+
+    if (ABLATE & 8) {   // keep the accumulators alive without the store tail
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[m][ns][r];
+        if (sum == 123.456f) a.out[tid] = sum;
+        return;
     }
 
     // ---- epilogue: D[row = pixel column, col = output channel]; lane holds channel j = lane&31 ----
     // and pixel columns xo(r) = (r&3) + 8*(r>>2) + 4*h for its 16 accumulator registers r.
+    // `full` (workgroup-uniform) selects a branch-free store tail for interior tiles.
     if (MODE == 2) {
-        constexpr int CB = COUT / NTILE;
-        const int tap = nb / CB, cb = nb - tap * CB;
-        const int kh = tap >> 1, kw = tap & 1;
+        const int kh = tap2 >> 1, kw = tap2 & 1;
         const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+        const bool full = (y0 + TILE_H <= a.Hc) && (x0 + TILE_W <= a.Wc);
+        auto tail = [&](auto guard_tag) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
-            const int co = cb * NTILE + ns * 32 + i;
-            const float b = a.bias[co];
+            for (int ns = 0; ns < 2; ++ns) {
+                const int co = cobase + ns * 32 + i;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int y = y0 + 2 * wave + m;
-                if (y >= a.Hc) continue;
-                float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo) * a.out_ps + a.out_coff + co;
+                for (int m = 0; m < 2; ++m) {
+                    const int y = y0 + 2 * wave + m;
+                    if (GUARD && y >= a.Hc) continue;
+                    float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo) * a.out_ps + a.out_coff + co;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (x < a.Wc) orow[(size_t)(2 * x + kw) * a.out_ps] = acc[m][ns][r] + b;
+                    for (int r = 0; r < 16; ++r) {
+                        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (!GUARD || x < a.Wc) orow[(size_t)(2 * x + kw) * a.out_ps] = acc[m][ns][r] + bias_v[ns];
+                    }
                 }
             }
-        }
+        };
+        if (full) tail(std::false_type{}); else tail(std::true_type{});
     } else {
+        const bool full = (y0 + TILE_H <= a.Hs) && (x0 + TILE_W <= a.Ws);
+        auto tail = [&](auto guard_tag) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
-            const int co = nb * NTILE + ns * 32 + i;
-            const float b = a.bias[co];
+            for (int ns = 0; ns < 2; ++ns) {
+                const int co = cobase + ns * 32 + i;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int y = y0 + 2 * wave + m;
-                if (y >= a.Hs) continue;
-                float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + co;
+                for (int m = 0; m < 2; ++m) {
+                    const int y = y0 + 2 * wave + m;
+                    if (GUARD && y >= a.Hs) continue;
+                    float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + co;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (x < a.Ws) orow[(size_t)x * a.out_ps] = fmaxf(acc[m][ns][r] + b, 0.f);
+                    for (int r = 0; r < 16; ++r) {
+                        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (!GUARD || x < a.Ws) orow[(size_t)x * a.out_ps] = fmaxf(acc[m][ns][r] + bias_v[ns], 0.f);
+                    }
                 }
             }
-            if (MODE == 1) {
-                // 2x2 max-pool, floor mode (nn.MaxPool2d(2,2), app.py:48,56): the four pixels of a
-                // window are registers (r, r+1) of the wave's two row tiles — no cross-lane traffic.
-                const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-                const int py = (y0 >> 1) + wave;
-                if (py < Hp) {
-                    float* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + co;
+        };
+        if (full) tail(std::false_type{}); else tail(std::true_type{});
+        if (MODE == 1) {
+            // 2x2 max-pool, floor mode (nn.MaxPool2d(2,2), app.py:48,56): the four pixels of a
+            // window are registers (r, r+1) of the wave's two row tiles — no cross-lane traffic.
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+            const int py = (y0 >> 1) + wave;
+            const bool pfull = (y0 + TILE_H <= a.Hc) && (x0 + TILE_W <= a.Wc);
+            auto ptail = [&](auto guard_tag) {
+                constexpr bool GUARD = decltype(guard_tag)::value;
+                if (GUARD && py >= Hp) return;
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns) {
+                    float* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase + ns * 32 + i;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int r = (q & 1) * 2 + (q >> 1) * 4;
                         const int px = (x0 >> 1) + (q & 1) + 4 * (q >> 1) + 2 * h;
                         const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
-                        if (px < Wp) prow[(size_t)px * COUT] = fmaxf(v + b, 0.f);
+                        if (!GUARD || px < Wp) prow[(size_t)px * COUT] = fmaxf(v + bias_v[ns], 0.f);
                     }
                 }
-            }
+            };
+            if (pfull) ptail(std::false_type{}); else ptail(std::true_type{});
         }
     }
 }
@@ -264,11 +335,13 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.in[((size_t)(n * 3 + c) * a.H + gy) * a.W + gx];
         lds[c * PLANE + hy * LW + hx] = v;
     }
-    float bw[2][14];
+    float bw[2][14], bias_v[2];
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
+    for (int ns = 0; ns < 2; ++ns) {
+        bias_v[ns] = a.bias[ns * 32 + i];   // loaded here, not in the store tail (see k_gemm_conv)
 #pragma unroll
         for (int s = 0; s < 14; ++s) bw[ns][s] = a.w[(ns * 14 + s) * 64 + lane];
+    }
     __syncthreads();
 
     f32x16 acc[2][2];
@@ -295,22 +368,25 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
                 acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], acc[m][ns], 0, 0, 0);
         }
     }
+    const bool full = (y0 + TILE_H <= a.H) && (x0 + TILE_W <= a.W);
+    auto tail = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
-        const int co = ns * 32 + i;
-        const float b = a.bias[co];
+        for (int ns = 0; ns < 2; ++ns) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = y0 + 2 * wave + m;
-            if (y >= a.H) continue;
-            float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64 + co;
+            for (int m = 0; m < 2; ++m) {
+                const int y = y0 + 2 * wave + m;
+                if (GUARD && y >= a.H) continue;
+                float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64 + ns * 32 + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (x < a.W) orow[(size_t)x * 64] = fmaxf(acc[m][ns][r] + b, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (!GUARD || x < a.W) orow[(size_t)x * 64] = fmaxf(acc[m][ns][r] + bias_v[ns], 0.f);
+                }
             }
         }
-    }
+    };
+    if (full) tail(std::false_type{}); else tail(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,83 @@
+// layer_bench.hip — timing experiments on single layers of the forward (not part of the product).
+// Build: make -C celebrity-image-denoiser_amd/csrc tools     Run on the GPU box: ./layer_bench
+// Each variant is run ROUNDS times, interleaved with the others in one process; prints median ms
+// and algorithmic TFLOP/s.  ABLATE variants compute wrong results by design (see conv_kernels.h).
+#include "../conv_kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace cid;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+struct Variant { std::string name; std::function<void(hipStream_t)> run; double flops; };
+
+static float* dalloc(size_t n, float scale) {
+    std::vector<float> h(n);
+    uint32_t s = 12345u + (uint32_t)n;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = scale * ((int)(s >> 8) % 2001 - 1000) / 1000.0f; }
+    float* d; CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+template <int CIN, int COUT, int MODE, int ABLATE, int WPS>
+static Variant make(const char* name, int N, int H, int W, float* in, float* w, float* bias, float* out, float* pool) {
+    GemmConvArgs a{};
+    a.in = in; a.w = w; a.bias = bias; a.out = out; a.pool = pool;
+    a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
+    a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
+    a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
+    const int grid = 8 * a.tiles_per_xcd * NB;
+    const double flops = 2.0 * CIN * COUT * (MODE == 2 ? 4 : 9) * (double)N * H * W;
+    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_gemm_conv<CIN, COUT, MODE, ABLATE, WPS>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? std::atoi(argv[1]) : 256;
+    const int ROUNDS = 7;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    // upconv1.0 shape: 128 -> 64 @ 128x128 ; bottleneck.2 shape: 256 -> 256 @ 32x32
+    float* inA = dalloc((size_t)N * 128 * 128 * 128, 1.f);
+    float* wA = dalloc((size_t)128 * 64 * 9, 0.05f);
+    float* bA = dalloc(64, 0.1f);
+    float* outA = dalloc((size_t)N * 128 * 128 * 64, 0.f);
+    float* poolA = dalloc((size_t)N * 64 * 64 * 64, 0.f);
+    float* inB = dalloc((size_t)N * 32 * 32 * 256, 1.f);
+    float* wB = dalloc((size_t)256 * 256 * 9, 0.05f);
+    float* bB = dalloc(256, 0.1f);
+    float* outB = dalloc((size_t)N * 32 * 32 * 256, 0.f);
+    std::vector<Variant> v;
+    v.push_back(make<128, 64, 0, 0, 2>("A 128->64@128  base wps2", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 0, 3>("A 128->64@128  base wps3", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 1, 2>("A no-halo-prefetch", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 2, 2>("A no-B-loads", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 4, 2>("A no-A-reads", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 8, 2>("A no-stores", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 7, 2>("A mfma+stores", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<128, 64, 0, 15, 2>("A mfma-only", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(make<256, 256, 0, 0, 2>("B 256->256@32  base wps2", N, 32, 32, inB, wB, bB, outB, nullptr));
+    v.push_back(make<256, 256, 0, 15, 2>("B mfma-only", N, 32, 32, inB, wB, bB, outB, nullptr));
+    v.push_back(make<128, 64, 1, 0, 2>("A' pool 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
+    std::vector<std::vector<float>> ms(v.size());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& x : v) x.run(s);   // warm-up
+    CK(hipStreamSynchronize(s));
+    for (int r = 0; r < ROUNDS; ++r)
+        for (size_t i = 0; i < v.size(); ++i) {
+            CK(hipEventRecord(e0, s)); v[i].run(s); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[i].push_back(t);
+        }
+    CK(hipGetLastError());
+    for (size_t i = 0; i < v.size(); ++i) {
+        std::sort(ms[i].begin(), ms[i].end());
+        const float med = ms[i][ms[i].size() / 2];
+        std::printf("%-28s median %8.4f ms  min %8.4f ms  %7.2f TFLOP/s  (%.1f%% of 157.3)\n", v[i].name.c_str(), med, ms[i][0],
+                    v[i].flops / (med * 1e-3) / 1e12, 100.0 * v[i].flops / (med * 1e-3) / 1e12 / 157.3);
+    }
+    return 0;
+}
