@@ -35,7 +35,7 @@ size_t ref_weight_count(const LayerDef& L) { return (size_t)L.cin * L.cout * (L.
 size_t packed_weight_count(const LayerDef& L) {
     switch (L.kind) {
         case HEAD: return 2 * 14 * 64;
-        case TAIL: return 2 * 9 * 8 * 12;
+        case TAIL: return 2 * 4 * 64 * 4;   // [chunk][group][lane][4], columns 27..31 stay zero
         default: return ref_weight_count(L);
     }
 }
@@ -64,9 +64,9 @@ size_t packed_index(const LayerDef& L, int co, int ci, int kh, int kw) {
             const int k = ci * 9 + kh * 3 + kw, s = k >> 1, h = k & 1;
             return (size_t)((co >> 5) * 14 + s) * 64 + h * 32 + (co & 31);
         }
-        case TAIL: {
-            const int tap = kh * 3 + kw, ck = ci >> 5, g = (ci >> 2) & 7, e = ci & 3;
-            return (size_t)((ck * 9 + tap) * 8 + g) * 12 + co * 4 + e;
+        case TAIL: {   // B[k = ci][col = 3*tap + co] of the tail's 64 x 32 product
+            const int col = (kh * 3 + kw) * 3 + co, ck = ci >> 5, g = (ci >> 3) & 3, h = (ci >> 2) & 1, e = ci & 3;
+            return (size_t)((ck * 4 + g) * 64 + h * 32 + col) * 4 + e;
         }
         case CONV:
         case CONVT: {

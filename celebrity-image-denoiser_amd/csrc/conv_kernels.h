@@ -17,7 +17,7 @@
 //     convolution's pixel scatter are all epilogues of the producing kernel — no pool, cat or
 //     copy kernel exists;
 //   * the 3-channel head (Cin=3, K=27) uses the same MFMA tile on a planar LDS image, and the
-//     3-channel tail (Cout=3) is a direct fp32 VALU convolution with scalar-broadcast weights.
+//     3-channel tail (Cout=3) runs as a 27-column (tap x cout) MFMA product plus a 9-way shifted sum.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -65,6 +65,46 @@ __device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd,
     nb = slot % NB;
     mt = xcd * tiles_per_xcd + slot / NB;
     return mt < tiles_total && slot / NB < tiles_per_xcd;
+}
+
+
+// ---- wide store tail -------------------------------------------------------------------------
+// An MFMA accumulator tile holds, per lane, ONE output channel and 16 pixels, so storing it
+// directly costs one 4-byte global store per register (two 128-byte segments per instruction).
+// Instead each wave transposes a [pixels][64 channels] slab through a private LDS staging area and
+// writes it as 16-byte stores: 16 consecutive lanes cover one pixel's 64 channels (256 contiguous
+// bytes), 4 pixels per instruction — a quarter of the store instructions at the same bytes.
+constexpr int WS_STRIDE = 68;                 // floats per staged pixel row (64 + 4: ds_write_b32 of 32 lanes conflict-free)
+constexpr int WS_FLOATS = 32 * WS_STRIDE;     // staging floats per wave
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stage NPIX (16 or 32) pixels x 64 channels and store them.  `val(ns, k)` gives the value of channel
+// 32*ns + (lane&31) for the k-th staged pixel of this lane (k in [0, NPIX/2)), `pix(k)` its pixel index
+// in [0, NPIX); `ptr(px)` returns the global address of channel 0 of the slab for pixel px, or nullptr
+// to skip it.
+template <int NPIX, typename ValFn, typename PixFn, typename PtrFn>
+__device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixFn pix, PtrFn ptr) {
+    const int i = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NPIX / 2; ++k) {
+        const int px = pix(k);
+        stg[px * WS_STRIDE + i] = val(0, k);
+        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < NPIX / 4; ++it) {
+        const int px = it * 4 + (lane >> 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 15) * 4);
+        float* g = ptr(px);
+        if (g) *reinterpret_cast<f32x4*>(g + (lane & 15) * 4) = v;
+    }
+    wave_lds_fence();
 }
 
 // MODE 0: 3x3 conv + bias + ReLU                      -> out (channel slice of a possibly wider buffer)
@@ -231,74 +271,50 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
     }
 
     // ---- epilogue: D[row = pixel column, col = output channel]; lane holds channel j = lane&31 ----
-    // and pixel columns xo(r) = (r&3) + 8*(r>>2) + 4*h for its 16 accumulator registers r.
-    // `full` (workgroup-uniform) selects a branch-free store tail for interior tiles.
+    // and pixel columns xo(r) = (r&3) + 8*(r>>2) + 4*h for its 16 accumulator registers r.  Each wave
+    // pushes its two tile rows (and the pooled row) through wide_store; the halo tile's LDS is free now.
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    static_assert(4 * WS_FLOATS * sizeof(float) <= sizeof(lds), "staging must fit in the halo tile's LDS");
+    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
     if (MODE == 2) {
         const int kh = tap2 >> 1, kw = tap2 & 1;
         const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
-        const bool full = (y0 + TILE_H <= a.Hc) && (x0 + TILE_W <= a.Wc);
-        auto tail = [&](auto guard_tag) {
-            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) {
-                const int co = cobase + ns * 32 + i;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int y = y0 + 2 * wave + m;
-                    if (GUARD && y >= a.Hc) continue;
-                    float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo) * a.out_ps + a.out_coff + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (!GUARD || x < a.Wc) orow[(size_t)(2 * x + kw) * a.out_ps] = acc[m][ns][r] + bias_v[ns];
-                    }
-                }
-            }
-        };
-        if (full) tail(std::false_type{}); else tail(std::true_type{});
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
+            const int step = 2 * a.out_ps;
+            const bool rowok = y < a.Hc;
+            wide_store<32>(stg, lane,
+                           [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; }, xo,
+                           [&](int px) -> float* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+        }
     } else {
-        const bool full = (y0 + TILE_H <= a.Hs) && (x0 + TILE_W <= a.Ws);
-        auto tail = [&](auto guard_tag) {
-            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) {
-                const int co = cobase + ns * 32 + i;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int y = y0 + 2 * wave + m;
-                    if (GUARD && y >= a.Hs) continue;
-                    float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (!GUARD || x < a.Ws) orow[(size_t)x * a.out_ps] = fmaxf(acc[m][ns][r] + bias_v[ns], 0.f);
-                    }
-                }
-            }
-        };
-        if (full) tail(std::false_type{}); else tail(std::true_type{});
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
+            const bool rowok = y < a.Hs;
+            wide_store<32>(stg, lane,
+                           [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); }, xo,
+                           [&](int px) -> float* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
+        }
         if (MODE == 1) {
             // 2x2 max-pool, floor mode (nn.MaxPool2d(2,2), app.py:48,56): the four pixels of a
             // window are registers (r, r+1) of the wave's two row tiles — no cross-lane traffic.
             const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
             const int py = (y0 >> 1) + wave;
-            const bool pfull = (y0 + TILE_H <= a.Hc) && (x0 + TILE_W <= a.Wc);
-            auto ptail = [&](auto guard_tag) {
-                constexpr bool GUARD = decltype(guard_tag)::value;
-                if (GUARD && py >= Hp) return;
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) {
-                    float* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase + ns * 32 + i;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = (q & 1) * 2 + (q >> 1) * 4;
-                        const int px = (x0 >> 1) + (q & 1) + 4 * (q >> 1) + 2 * h;
-                        const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
-                        if (!GUARD || px < Wp) prow[(size_t)px * COUT] = fmaxf(v + bias_v[ns], 0.f);
-                    }
-                }
-            };
-            if (pfull) ptail(std::false_type{}); else ptail(std::true_type{});
+            float* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase;
+            const bool rowok = py < Hp;
+            wide_store<16>(stg, lane,
+                           [&](int ns, int q) {
+                               const int r = (q & 1) * 2 + (q >> 1) * 4;
+                               const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
+                               return fmaxf(v + bias_v[ns], 0.f);
+                           },
+                           [&](int q) { return (q & 1) + 4 * (q >> 1) + 2 * h; },
+                           [&](int px) -> float* { return (rowok && (x0 >> 1) + px < Wp) ? prow + (size_t)((x0 >> 1) + px) * COUT : nullptr; });
         }
     }
 }
@@ -318,7 +334,8 @@ struct HeadArgs {
 
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;   // 34 used columns, padded to 36
-    __shared__ float lds[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) float lds[4 * WS_FLOATS];   // input planes (3*PLANE floats), then store staging
+    static_assert(3 * PLANE <= 4 * WS_FLOATS, "lds");
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
     const int tx = mt % a.tiles_x;
@@ -368,36 +385,31 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
                 acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], acc[m][ns], 0, 0, 0);
         }
     }
-    const bool full = (y0 + TILE_H <= a.H) && (x0 + TILE_W <= a.W);
-    auto tail = [&](auto guard_tag) {
-        constexpr bool GUARD = decltype(guard_tag)::value;
+    __syncthreads();   // all A reads of the input planes are done: the LDS becomes store staging
+    float* stg = lds + wave * WS_FLOATS;
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int y = y0 + 2 * wave + m;
-                if (GUARD && y >= a.H) continue;
-                float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64 + ns * 32 + i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (!GUARD || x < a.W) orow[(size_t)x * 64] = fmaxf(acc[m][ns][r] + bias_v[ns], 0.f);
-                }
-            }
-        }
-    };
-    if (full) tail(std::false_type{}); else tail(std::true_type{});
+    for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64;
+        const bool rowok = y < a.H;
+        wide_store<32>(stg, lane,
+                       [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); },
+                       [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; },
+                       [&](int px) -> float* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Tail: upconv1[2] = Conv2d(64, 3, 3, padding=1) followed by torch.tanh  (app.py:77,101,103).
-// N = 3 is not a GEMM: one output pixel per lane, three fp32 accumulators, the pixel's
-// neighbourhood read from the swizzled LDS halo tile as 16-byte vectors and the weights
-// broadcast from scalar registers.  Memory-bound on its 64-channel NHWC input; writes the
-// caller's NCHW output directly (the NHWC -> NCHW change of layout is folded into this kernel).
+// Cout = 3 is no GEMM, but (tap, cout) = 27 columns is: the kernel first computes, for every pixel p
+// of the 10x34 halo tile, z[p][3*tap + co] = sum_ci x[p][ci] * W[co][ci][tap] as a [352 x 64] x [64 x 32]
+// MFMA product (27 of 32 columns used; weights held in 32 registers), parks z in the LDS the input
+// tile occupied, and then every output pixel adds its nine shifted z entries, the bias, applies
+// tanh and is written straight into the caller's NCHW tensor (the NHWC -> NCHW change of layout is
+// folded in).  HBM-bound on the 64-channel NHWC input it reads once.
 struct TailArgs {
     const float* in;    // NHWC [N,H,W,64]
-    const float* w;     // packed [2 chunk][9 tap][8 group][3 co][4 ci]
+    const float* w;     // packed [2 chunk][4 group][64 lanes][4]  (cid_api.hip packed_index, TAIL)
     const float* bias;  // [3]
     float* out;         // NCHW [N,3,H,W]
     int N, H, W;
@@ -405,60 +417,98 @@ struct TailArgs {
 };
 
 __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
-    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH, NSLOT = LPIX * 8;
-    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;
-    __shared__ f32x4 lds[LPIX * PSLOTS];
+    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;   // 340 halo pixels
+    constexpr int MT = (LPIX + 31) / 32, LP = MT * 32;                // 11 M tiles, 352 rows
+    constexpr int NSLOT = LPIX * 8, NLOAD = (NSLOT + THREADS - 1) / THREADS;
+    constexpr int ZS = 33;                                            // z row stride in floats (conflict-free)
+    __shared__ f32x4 lds[LP * PSLOTS];
+    static_assert(LP * ZS * sizeof(float) <= sizeof(lds), "z must fit where x was");
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
     const int tx = mt % a.tiles_x;
     const int ty = (mt / a.tiles_x) % a.tiles_y;
     const int n = mt / (a.tiles_x * a.tiles_y);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const int tid = threadIdx.x;
-    const int row = tid >> 5, col = tid & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
 
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    const int pb = row * LW + col;
+    f32x4 wb[2][4];
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wb[ck][g] = reinterpret_cast<const f32x4*>(a.w)[(ck * 4 + g) * 64 + lane];
+    float bias_v[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bias_v[co] = a.bias[co];
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const float* inb = a.in + (size_t)n * a.H * a.W * 64;
+#pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
-        __syncthreads();
+        f32x4 stage[NLOAD];
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it) {
             const int s = it * THREADS + tid;
-            if (s < NSLOT) {
-                const int p = s >> 3, c = s & 7;
-                const int hy = p / LW, hx = p - hy * LW;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(n * a.H + gy) * a.W + gx) * 64 + ck * KCHUNK + c * 4);
-                lds[lds_slot(p, c)] = v;
-            }
+            const int p = s >> 3, c = s & 7;
+            const int hy = p / LW, hx = p - hy * LW;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = (s < NSLOT) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            f32x4 v = *reinterpret_cast<const f32x4*>(inb + (ok ? ((gy * a.W + gx) * 64 + c * 4) : 0) + ck * KCHUNK);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            stage[it] = v;
+        }
+        if (ck > 0) __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            if (s < NSLOT) lds[lds_slot(s >> 3, s & 7)] = stage[it];
         }
         __syncthreads();
-        const float* wk = a.w + ck * (9 * 8 * 12);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int p = pb + (tap / 3) * LW + (tap % 3);
+        for (int t = 0; t < 3; ++t) {
+            const int mtile = wave + 4 * t;          // wave-uniform
+            if (mtile < MT) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const f32x4 x = lds[lds_slot(p, g)];
-                const float* wv = wk + (tap * 8 + g) * 12;   // wave-uniform -> scalar loads
+                for (int g = 0; g < 4; ++g) {
+                    // rows 340..351 of the last tile read never-written LDS: they only reach z rows nobody gathers
+                    const f32x4 av = lds[lds_slot(mtile * 32 + i, 2 * g + h)];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc0 = fmaf(x[e], wv[e], acc0);
-                    acc1 = fmaf(x[e], wv[4 + e], acc1);
-                    acc2 = fmaf(x[e], wv[8 + e], acc2);
+                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[ck][g][e], acc[t], 0, 0, 0);
                 }
             }
         }
     }
+    __syncthreads();   // every wave is done reading x: the LDS becomes z[352][33]
+    float* zl = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int mtile = wave + 4 * t;
+        if (mtile < MT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zl[(mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ZS + i] = acc[t][r];
+        }
+    }
+    __syncthreads();
+    const int row = tid >> 5, col = tid & 31;
+    const int pb = row * LW + col;
+    float o[3] = {bias_v[0], bias_v[1], bias_v[2]};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* zp = zl + (pb + (tap / 3) * LW + (tap % 3)) * ZS + tap * 3;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) o[co] += zp[co];
+    }
     const int y = y0 + row, x = x0 + col;
     if (y < a.H && x < a.W) {
         const size_t plane = (size_t)a.H * a.W;
-        float* o = a.out + (size_t)n * 3 * plane + (size_t)y * a.W + x;
-        o[0] = tanhf(acc0 + a.bias[0]);
-        o[plane] = tanhf(acc1 + a.bias[1]);
-        o[2 * plane] = tanhf(acc2 + a.bias[2]);
+        float* op = a.out + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+        op[0] = tanhf(o[0]);
+        op[plane] = tanhf(o[1]);
+        op[2 * plane] = tanhf(o[2]);
     }
 }
 
