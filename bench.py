@@ -203,6 +203,19 @@ def main():
                              "tolerance": "max|delta|<=1e-5, psnr_delta<=0.01 dB"}
         except Exception as e:  # pragma: no cover
             res["parity"] = {"error": str(e)[:200]}
+        # host-buffer round trip (pinned H2D of the batch + forward + D2H of the result): reported, never `value`
+        try:
+            xh = torch.from_numpy(x_host).pin_memory()
+            yh = torch.empty(tuple(y.shape), dtype=torch.float32).pin_memory()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                yh.copy_(model(xh.to(dev, non_blocking=True)), non_blocking=True)
+            torch.cuda.synchronize(dev)
+            res["pcie_inclusive"] = {"images_per_sec": round(3 * B / (time.perf_counter() - t1), 1),
+                                     "note": "per step: H2D 50 MB fp32 NCHW + forward + D2H 50 MB, pinned host buffers, rank 0 only"}
+        except Exception as e:  # pragma: no cover
+            res["pcie_inclusive"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(res))

@@ -1,0 +1,128 @@
+"""No-GPU checks of the C ABI: libcid.so loads, exports every symbol include/cid.h declares, and its
+host-only entry points (weight staging, shape/workspace planning, work tables) behave.  No compute call."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from celebrity_image_denoiser_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cid.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cid_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_header_symbol():
+    names = _declared_symbols()
+    assert len(names) >= 20
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/cid.h but not exported by libcid.so"
+    assert set(names) == set(_lib.SYMBOLS), "python binding table and header disagree"
+
+
+def test_version_and_tables():
+    L = _lib.lib()
+    assert b"gfx950" in L.cid_version()
+    keys = [L.cid_param_key(i).decode() for i in range(_lib.CID_NUM_PARAMS)]
+    assert keys == list(synth.param_shapes().keys())          # reference state_dict order, app.py:42-78
+    assert L.cid_param_key(24) is None
+    assert [L.cid_launch_name(i).decode() for i in range(12)] == [name for name, *_ in synth.LAYERS]
+
+
+def test_out_shape_and_workspace():
+    L = _lib.lib()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    for (h, w), exp in {(128, 128): (128, 128), (127, 130): (124, 128), (13, 18): (12, 16), (4, 4): (4, 4), (7, 9): (4, 8)}.items():
+        assert L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) == 0
+        assert (ho.value, wo.value) == exp
+    assert L.cid_out_shape(3, 8, ctypes.byref(ho), ctypes.byref(wo)) == 2      # CID_ERR_SHAPE
+    n = ctypes.c_size_t()
+    assert L.cid_workspace_bytes(256, 128, 128, ctypes.byref(n)) == 0
+    per_img = 128 * 128 * (64 + 128 + 64) + 64 * 64 * (64 + 128 + 256 + 128 + 128) + 32 * 32 * (128 + 256 + 256)
+    assert n.value == 256 * per_img * 4                                          # NHWC fp32 arena, DESIGN.md
+    assert L.cid_workspace_bytes(0, 128, 128, ctypes.byref(n)) == 2
+
+
+def test_algorithmic_work_matches_survey():
+    """11,521,753,088 FLOP per 128x128 image, 46,087,012,352 per 256x256."""
+    L = _lib.lib()
+    f, b = ctypes.c_double(), ctypes.c_double()
+    tot = 0.0
+    for i in range(12):
+        assert L.cid_launch_work(i, 1, 128, 128, ctypes.byref(f), ctypes.byref(b)) == 0
+        tot += f.value
+    assert tot == 11521753088.0
+    tot = sum((L.cid_launch_work(i, 1, 256, 256, ctypes.byref(f), ctypes.byref(b)), f.value)[1] for i in range(12))
+    assert tot == 46087012352.0
+    L.cid_launch_work(0, 1, 128, 128, ctypes.byref(f), ctypes.byref(b))
+    assert b.value == 4390912 + (3 * 64 * 9 + 64) * 4      # a1: 4,390,912 activation bytes/img + weights
+
+
+def test_weight_staging_roundtrip_and_errors():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.cid_create(ctypes.byref(h)) == 0
+    miss = ctypes.c_int()
+    L.cid_missing_weights(h, ctypes.byref(miss))
+    assert miss.value == 24
+    sd = synth.make_state_dict("hot")
+    for k, v in sd.items():
+        shape = (ctypes.c_int64 * v.ndim)(*v.shape)
+        assert L.cid_set_weight(h, k.encode(), v.ctypes.data, shape, v.ndim) == 0
+    L.cid_missing_weights(h, ctypes.byref(miss))
+    assert miss.value == 0
+    for k, v in sd.items():                                   # unpack(pack(w)) == w for every layer layout
+        out = np.empty_like(v)
+        assert L.cid_get_weight(h, k.encode(), out.ctypes.data, out.size) == 0
+        assert np.array_equal(out, v), k
+    w = sd["up2.weight"]
+    bad = (ctypes.c_int64 * 4)(128, 256, 2, 2)               # Conv2d-style dims for a ConvTranspose2d weight
+    assert L.cid_set_weight(h, b"up2.weight", w.ctypes.data, bad, 4) == 2
+    assert b"size mismatch for up2.weight" in L.cid_last_error(h)
+    assert L.cid_set_weight(h, b"down3.0.weight", w.ctypes.data, bad, 4) == 3
+    assert b"unexpected key" in L.cid_last_error(h)
+    # packed blob export/import carries the same tensors to another handle
+    nbytes = L.cid_packed_weights_bytes()
+    blob = np.empty(nbytes, np.uint8)
+    assert L.cid_export_packed(h, blob.ctypes.data, nbytes) == 0
+    h2 = ctypes.c_void_p()
+    L.cid_create(ctypes.byref(h2))
+    assert L.cid_import_packed(h2, blob.ctypes.data, nbytes) == 0
+    assert L.cid_import_packed(h2, blob.ctypes.data, nbytes - 4) == 2
+    out = np.empty_like(sd["bottleneck.2.weight"])
+    L.cid_get_weight(h2, b"bottleneck.2.weight", out.ctypes.data, out.size)
+    assert np.array_equal(out, sd["bottleneck.2.weight"])
+    # forward without device weights is refused with a message, not a crash (no GPU touched)
+    dummy = np.zeros(16, np.float32)
+    rc = L.cid_forward(h2, dummy.ctypes.data, dummy.ctypes.data, 1, 8, 8, dummy.ctypes.data, 64, None)
+    assert rc == 4 and b"no device weights" in L.cid_last_error(h2)
+    L.cid_destroy(h)
+    L.cid_destroy(h2)
+
+
+def test_packed_layout_of_a_gemm_layer():
+    """Spot-check the documented packed order [nb][chunk][tap][g][ns][lane][e] against the reference
+    tensor for down2.0 (Conv2d 64->128): lane (h, j) of step (chunk, tap, g) holds
+    W[co = 64 nb + 32 ns + j][ci = 32 chunk + 8 g + 4 h + e][kh][kw]."""
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    L.cid_create(ctypes.byref(h))
+    w = synth.make_state_dict("default")["down2.0.weight"]
+    shape = (ctypes.c_int64 * 4)(*w.shape)
+    assert L.cid_set_weight(h, b"down2.0.weight", w.ctypes.data, shape, 4) == 0
+    blob = np.empty(L.cid_packed_weights_bytes(), np.uint8)
+    L.cid_export_packed(h, blob.ctypes.data, blob.nbytes)
+    f = blob.view(np.float32)
+    # offset of layer 2's weights: after head (w 1792 -> 1792, b 64) and down1.2 (w 36864, b 64), 64-float aligned
+    off = 1792 + 64 + 36864 + 64
+    nb, ck, tap, g, ns, hh, j, e = 1, 1, 5, 2, 1, 1, 17, 3
+    idx = ((((nb * 2 + ck) * 9 + tap) * 4 + g) * 2 + ns) * 256 + (hh * 32 + j) * 4 + e
+    assert f[off + idx] == w[64 * nb + 32 * ns + j, 32 * ck + 8 * g + 4 * hh + e, tap // 3, tap % 3]
+    L.cid_destroy(h)

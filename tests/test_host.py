@@ -1,0 +1,111 @@
+"""Host-side mirror of the reference interface, without a GPU: construction, state_dict names and
+shapes, checkpoint unwrapping (load_state_safely semantics), strictness, loud failure without a GPU,
+synthetic data recipe, PSNR definition, shard arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import celebrity_image_denoiser_amd as cid
+from celebrity_image_denoiser_amd import api, dist as cdist, synth
+
+
+def test_module_surface_matches_reference_keys():
+    m = cid.DenoiseGenerator()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(synth.param_shapes().keys())
+    assert {k: tuple(v.shape) for k, v in sd.items()} == dict(synth.param_shapes())
+    assert sum(v.numel() for v in sd.values()) == 1827587
+    assert m.eval() is m
+    assert isinstance(m, torch.nn.Module)
+
+
+def test_checkpoint_unwrapping_like_load_state_safely(tmp_path):
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("hot").items()}
+    # (i) trainer layout {"generator": sd, ...} (training.py:359-376), (ii) bare, (iii) "module."-prefixed
+    for ckpt in ({"generator": sd, "epoch": 3}, sd, {"state_dict": {"module." + k: v for k, v in sd.items()}}, {"G": sd}):
+        got = api.extract_state_dict(ckpt)
+        assert list(got.keys()) == list(sd.keys())
+    path = os.path.join(tmp_path, "denoise_epoch_499.pth")
+    torch.save({"generator": {"module." + k: v for k, v in sd.items()}, "epoch": 499}, path)
+    m = cid.DenoiseGenerator()
+    api.load_state_safely(m, path)
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    assert not m.training
+
+
+def test_strict_and_non_strict_loading():
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("default").items()}
+    m = cid.DenoiseGenerator()
+    partial = {k: v for k, v in sd.items() if not k.startswith("up1")}
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(partial, strict=True)
+    res = m.load_state_dict(partial, strict=False)                   # app.py:272 uses strict=False
+    assert sorted(res.missing_keys) == ["up1.bias", "up1.weight"]
+    with pytest.raises(RuntimeError):                                # wrong shape is an error even non-strict
+        m.load_state_dict({"up2.weight": torch.zeros(128, 256, 2, 2)}, strict=False)
+
+
+def test_no_cpu_fallback():
+    m = cid.DenoiseGenerator()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError):
+        m.pack_weights()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU"):
+            cid.load(None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from celebrity_image_denoiser_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcid.so")
+    with pytest.raises(RuntimeError, match="not built"):
+        _lib.lib()
+
+
+def test_host_packed_blob_roundtrip_refreshes_parameters():
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("hot").items()}
+    a, b = cid.DenoiseGenerator(), cid.DenoiseGenerator()
+    a.load_state_dict(sd)
+    b.adopt_packed_weights(a.pack_weights_host())
+    assert all(torch.equal(b.state_dict()[k], sd[k]) for k in sd)
+    with pytest.raises(ValueError):
+        b.adopt_packed_weights(torch.zeros(16, dtype=torch.uint8))
+
+
+def test_synthetic_data_recipe():
+    x, clean, noisy = synth.make_batch(2, 32, 48, first_index=5)
+    assert x.shape == (2, 3, 32, 48) and x.dtype == np.float32 and noisy.dtype == np.uint8
+    assert x.min() >= -1 and x.max() <= 1
+    # x = (u8/255 - 0.5)/0.5 in float32 (app.py:401-405)
+    assert np.array_equal(x, ((noisy.astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5)).transpose(0, 3, 1, 2))
+    x2, _, _ = synth.make_batch(1, 32, 48, first_index=6)
+    assert np.array_equal(x2[0], x[1])                               # image index, not batch position, seeds an image
+    d = noisy.astype(np.float64) - synth.clean_images_u8(2, 32, 48, 5)
+    assert 15 < d.std() < 30                                         # sigma = 25 before clipping (noise_generation.py:6-10)
+    a, b = synth.make_state_dict("default"), synth.make_state_dict("hot")
+    assert abs(a["down2.0.weight"]).max() <= 1 / np.sqrt(64 * 9) and abs(b["down2.0.weight"]).max() > 1 / np.sqrt(64 * 9)
+
+
+def test_psnr_definition():
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, (3, 3, 8, 8)).astype(np.float32)
+    b = a + rng.normal(0, 0.1, a.shape).astype(np.float32)
+    mse = ((a.astype(np.float64) - b) ** 2).reshape(3, -1).mean(1)
+    assert abs(cid.psnr(a, b) - np.mean(10 * np.log10(4.0 / mse))) < 1e-12   # data_range=2.0, training.py:382
+    assert cid.psnr(torch.from_numpy(a), torch.from_numpy(a)) == float("inf")
+
+
+def test_shard_range_partitions_the_batch():
+    for n, w in ((2048, 8), (256, 1), (10, 4), (3, 8), (0, 2)):
+        spans = [cdist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+    assert cdist.shard_range(2048, 3, 8) == (768, 1024)              # config 3: 256 images per GPU
+    with pytest.raises(ValueError):
+        cdist.shard_range(8, 2, 2)
