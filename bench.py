@@ -163,7 +163,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/collect_pmc.sh (separate --pmc passes)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(d["kernel"])
+                tr = json.load(open(pmc))
+                traffic = next((v for k, v in tr.items() if k.startswith(d["kernel"])), None)
             except Exception:
                 traffic = None
         if d["bound"] == "mfma":
