@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--weights", default="default", choices=["default", "hot"])
+    ap.add_argument("--algo", default="winograd", choices=["winograd", "direct"],
+                    help="algorithm of the eight 3x3 GEMM layers (both fp32; default Winograd F(2x2,3x3))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,6 +117,7 @@ def main():
     sd = synth.make_state_dict(args.weights)
     # rank 0 owns the checkpoint; everyone else starts from its own random init and receives the blob
     model = cid.load(sd if rank == 0 else None, device=dev, strict=True)
+    model.conv_algo = args.algo
     if world > 1:
         cdist.broadcast_weights(model, src=0)
 
@@ -148,7 +151,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        table = launch_table(end - begin, S, S)
+        table = launch_table(end - begin, S, S, model)
         layers = []
         for (name, kern, flops, nbytes), ms_sum in zip(table, launch_ms):
             ms = ms_sum / max(nfw, 1)
@@ -186,7 +189,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch={B} per GPU, {S}x{S}x3 fp32 forward, HIP conv kernels"
                                    + (f" (global batch {B * world} sharded over {world} GPUs, configs[2] shape)" if world > 1 else ""),
-                       "global_batch": B * world, "image": [S, S, 3], "weights": f"synthetic seeded ({args.weights})",
+                       "global_batch": B * world, "image": [S, S, 3], "weights": f"synthetic seeded ({args.weights})", "conv3x3_algo": args.algo,
                        "parallelism": f"dp{world}", "inputs": "resident in HBM"},
             "whole_net_tflops": round(total_flops * args.steps / elapsed / 1e12 * 1.0, 2),
             "whole_net_frac_of_f32_mfma_peak": round(total_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

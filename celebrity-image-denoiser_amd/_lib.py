@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libcid.so")
 CID_OK = 0
 CID_NUM_PARAMS = 24
 CID_NUM_LAUNCHES = 12
+CID_ALGO_DIRECT, CID_ALGO_WINOGRAD = 0, 1
 
 # every symbol include/cid.h declares: (restype, argtypes)
 _c = ctypes
@@ -36,7 +37,9 @@ SYMBOLS = {
     "cid_timing_begin": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_timing_end": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
     "cid_launch_name": (_c.c_char_p, [_c.c_int]),
-    "cid_launch_kernel": (_c.c_char_p, [_c.c_int]),
+    "cid_launch_kernel": (_c.c_char_p, [_c.c_void_p, _c.c_int]),
+    "cid_set_conv_algo": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "cid_get_conv_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_launch_work": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 

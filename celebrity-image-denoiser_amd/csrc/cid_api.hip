@@ -4,6 +4,7 @@
 // Layer table = the reference module's declaration order, backend/app.py:42-78.
 #include "../../include/cid.h"
 #include "conv_kernels.h"
+#include "wino_kernels.h"
 
 #include <cstdio>
 #include <cstring>
@@ -29,6 +30,12 @@ const char* kKernelNames[NL] = {
     "k_gemm_conv<128, 128, 0,", "k_gemm_conv<128, 64, 2,", "k_gemm_conv<128, 64, 0,", "k_conv_tail",
 };
 
+const char* kWinoKernelNames[NL] = {
+    nullptr, "k_wino_conv<64, 64, true,", "k_wino_conv<64, 128, false,", "k_wino_conv<128, 128, true,",
+    "k_wino_conv<128, 256, false,", "k_wino_conv<256, 256, false,", nullptr, "k_wino_conv<256, 128, false,",
+    "k_wino_conv<128, 128, false,", nullptr, "k_wino_conv<128, 64, false,", nullptr,
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t ref_weight_count(const LayerDef& L) { return (size_t)L.cin * L.cout * (L.kind == CONVT ? 4 : 9); }
@@ -41,13 +48,24 @@ size_t packed_weight_count(const LayerDef& L) {
 }
 
 // float offsets of each layer's packed weights / bias inside the blob; segments 256-byte aligned
+//   [direct-kernel segments][Winograd U of the eight 3x3 GEMM layers][reference-layout copy of all 24 tensors]
+// The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
+// not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], raw_w_off[NL], raw_b_off[NL], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
             w_off[l] = o; o = align_up(o + packed_weight_count(kLayers[l]), 64);
             b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
+        }
+        for (int l = 0; l < NL; ++l) {
+            u_off[l] = o;
+            if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 16, 64);
+        }
+        for (int l = 0; l < NL; ++l) {
+            raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
+            raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
         total = o;
     }
@@ -87,6 +105,27 @@ size_t ref_index(const LayerDef& L, int co, int ci, int kh, int kw) {
     return (((size_t)co * L.cin + ci) * 3 + kh) * 3 + kw;
 }
 
+// Winograd F(2x2,3x3) filter transform U = G g G^T (reference Conv2d weight [Cout,Cin,3,3] -> 16 values per
+// (co, ci)), in double, rounded once to fp32, laid out for wino_kernels.h:
+//   [nb = co/32][chunk = ci/16][round = (ci/8)%2][a][b][lane = 32*h + j][e],  ci = 16*chunk + 8*round + 4*h + e, co = 32*nb + j
+void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nchunk = L.cin / 16;
+    for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < L.cin; ++ci) {
+            const float* g = w + ((size_t)co * L.cin + ci) * 9;
+            double tmp[4][3];
+            for (int a = 0; a < 4; ++a)
+                for (int q = 0; q < 3; ++q) tmp[a][q] = G[a][0] * g[0 * 3 + q] + G[a][1] * g[1 * 3 + q] + G[a][2] * g[2 * 3 + q];
+            const int nb = co >> 5, j = co & 31, ck = ci >> 4, g2 = (ci >> 3) & 1, h = (ci >> 2) & 1, e = ci & 3;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+                    dst[((((((size_t)nb * nchunk + ck) * 2 + g2) * 4 + a) * 4 + b) * 64 + h * 32 + j) * 4 + e] = (float)u;
+                }
+        }
+}
+
 struct Dims {
     int N, H, W, H1, W1, H2, W2, Hu2, Wu2, Hu1, Wu1;
 };
@@ -118,6 +157,7 @@ struct cid_handle_s {
     bool have[NL][2];
     const float* dev_blob = nullptr;
     std::string err;
+    int algo = CID_ALGO_WINOGRAD;      // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
     cid_handle_s() : staging(kBlob.total, 0.f) { std::memset(have, 0, sizeof(have)); }
@@ -176,6 +216,30 @@ hipError_t launch_gemm(hipStream_t s, const float* blob, int layer, const float*
     return hipGetLastError();
 }
 
+template <int CIN, int COUT, bool POOL, int TC>
+hipError_t launch_wino_tc(hipStream_t s, const WinoArgs& base) {
+    WinoArgs a = base;
+    constexpr int BTR = 2 * (32 / TC);
+    a.tiles_x = cdiv(a.Wc, 2 * TC); a.tiles_y = cdiv(a.Hc, 2 * BTR);
+    a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
+    hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN)), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// One 3x3 GEMM layer, by the handle's algorithm: MODE 0/1 of k_gemm_conv or Winograd.
+template <int CIN, int COUT, int MODE>
+hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer, const float* in, int Hin, int Win, int in_ps,
+                          float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
+    if (algo == 0) return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+    WinoArgs a;
+    a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.out = out; a.pool = pool;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
+    a.out_ps = out_ps; a.out_coff = out_coff;
+    a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
+    // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
+    return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
+}
+
 hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid) {
     hipLaunchKernelGGL(k_conv_head, dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
@@ -225,23 +289,23 @@ int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W
         STEP(launch_head(s, a, 8 * g.per_xcd));
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
-    STEP((launch_gemm<64, 64, 1>(s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
+    STEP((launch_conv3x3<64, 64, 1>(h->algo, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
     // down2[0] + ReLU                                                                    app.py:51-52
-    STEP((launch_gemm<64, 128, 0>(s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
+    STEP((launch_conv3x3<64, 128, 0>(h->algo, s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
     // down2[2] + ReLU -> e2 into cat2[:, 128:256] (cropped), pool2 -> p2                 app.py:53-56,90-93
-    STEP((launch_gemm<128, 128, 1>(s, blob, 3, B[T1], d.H1, d.W1, 128, B[CAT2], 256, 128, d.Hu2, d.Wu2, d.Hu2, d.Wu2, B[P2], N)));
+    STEP((launch_conv3x3<128, 128, 1>(h->algo, s, blob, 3, B[T1], d.H1, d.W1, 128, B[CAT2], 256, 128, d.Hu2, d.Wu2, d.Hu2, d.Wu2, B[P2], N)));
     // bottleneck                                                                         app.py:59-62
-    STEP((launch_gemm<128, 256, 0>(s, blob, 4, B[P2], d.H2, d.W2, 128, B[T2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
-    STEP((launch_gemm<256, 256, 0>(s, blob, 5, B[T2], d.H2, d.W2, 256, B[BT], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_conv3x3<128, 256, 0>(h->algo, s, blob, 4, B[P2], d.H2, d.W2, 128, B[T2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_conv3x3<256, 256, 0>(h->algo, s, blob, 5, B[T2], d.H2, d.W2, 256, B[BT], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
     // up2: ConvT 256->128 -> cat2[:, 0:128]                                              app.py:65,89
     STEP((launch_gemm<256, 128, 2>(s, blob, 6, B[BT], d.H2, d.W2, 256, B[CAT2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
     // upconv2                                                                            app.py:67-70
-    STEP((launch_gemm<256, 128, 0>(s, blob, 7, B[CAT2], d.Hu2, d.Wu2, 256, B[T3], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
-    STEP((launch_gemm<128, 128, 0>(s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_conv3x3<256, 128, 0>(h->algo, s, blob, 7, B[CAT2], d.Hu2, d.Wu2, 256, B[T3], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_conv3x3<128, 128, 0>(h->algo, s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // up1: ConvT 128->64 -> cat1[:, 0:64]                                                app.py:73,96
     STEP((launch_gemm<128, 64, 2>(s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // upconv1[0] + ReLU                                                                  app.py:75-76
-    STEP((launch_gemm<128, 64, 0>(s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
+    STEP((launch_conv3x3<128, 64, 0>(h->algo, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
     {   // upconv1[2] + tanh, NHWC t4 -> NCHW out                                         app.py:77,103
         TailArgs a;
         a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
@@ -259,7 +323,7 @@ int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W
 
 extern "C" {
 
-const char* cid_version(void) { return "cid 0.1.0 (gfx950, fp32 MFMA implicit-GEMM)"; }
+const char* cid_version(void) { return "cid 0.2.0 (gfx950, fp32 MFMA: Winograd F(2x2,3x3) + implicit GEMM)"; }
 
 int cid_create(cid_handle_t* out) {
     if (!out) return CID_ERR_INVALID;
@@ -302,9 +366,12 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
     }
     if (is_bias) {
         std::memcpy(h->staging.data() + kBlob.b_off[l], data, sizeof(float) * L.cout);
+        std::memcpy(h->staging.data() + kBlob.raw_b_off[l], data, sizeof(float) * L.cout);
     } else {
         float* dst = h->staging.data() + kBlob.w_off[l];
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
+        std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
+        if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l]);
     }
     h->have[l][is_bias] = true;
     return CID_OK;
@@ -318,12 +385,8 @@ int cid_get_weight(cid_handle_t h, const char* key, float* out, size_t count) {
     const LayerDef& L = kLayers[l];
     const size_t need = is_bias ? (size_t)L.cout : ref_weight_count(L);
     if (count != need) return fail(h, CID_ERR_SHAPE, std::string("cid_get_weight: wrong element count for ") + key);
-    if (is_bias) {
-        std::memcpy(out, h->staging.data() + kBlob.b_off[l], sizeof(float) * L.cout);
-    } else {
-        const float* src = h->staging.data() + kBlob.w_off[l];
-        for_each_weight(L, [&](int co, int ci, int kh, int kw) { out[ref_index(L, co, ci, kh, kw)] = src[packed_index(L, co, ci, kh, kw)]; });
-    }
+    // the blob carries a reference-layout copy of every tensor (the Winograd U is not invertible bit-for-bit)
+    std::memcpy(out, h->staging.data() + (is_bias ? kBlob.raw_b_off[l] : kBlob.raw_w_off[l]), sizeof(float) * need);
     return CID_OK;
 }
 
@@ -455,7 +518,22 @@ int cid_forward_timed(cid_handle_t h, const float* in, float* out, int N, int H,
 }
 
 const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name : nullptr; }
-const char* cid_launch_kernel(int i) { return (i >= 0 && i < NL) ? kKernelNames[i] : nullptr; }
+const char* cid_launch_kernel(cid_handle_t h, int i) {
+    if (i < 0 || i >= NL) return nullptr;
+    return (h && h->algo == 1 && kWinoKernelNames[i]) ? kWinoKernelNames[i] : kKernelNames[i];
+}
+
+int cid_set_conv_algo(cid_handle_t h, int algo) {
+    if (!h) return CID_ERR_INVALID;
+    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
+    h->algo = algo;
+    return CID_OK;
+}
+int cid_get_conv_algo(cid_handle_t h, int* algo) {
+    if (!h || !algo) return CID_ERR_INVALID;
+    *algo = h->algo;
+    return CID_OK;
+}
 
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes) {
     if (i < 0 || i >= NL || !flops || !bytes) return CID_ERR_INVALID;

@@ -184,6 +184,20 @@ class DenoiseGenerator(nn.Module):
         return y, list(ms)
 
 
+    @property
+    def conv_algo(self) -> str:
+        """"winograd" (default; F(2x2,3x3) on MFMA) or "direct" (9-tap implicit GEMM) for the 3x3 GEMM layers."""
+        a = ctypes.c_int()
+        _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
+        return "winograd" if a.value == _lib.CID_ALGO_WINOGRAD else "direct"
+
+    @conv_algo.setter
+    def conv_algo(self, name: str) -> None:
+        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd": _lib.CID_ALGO_WINOGRAD}.get(name)
+        if algo is None:
+            raise ValueError("conv_algo must be 'direct' or 'winograd'")
+        _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
+
     def timing_begin(self, max_forwards: int) -> None:
         """Arm per-launch HIP-event timing for the next `max_forwards` forwards (no per-forward sync)."""
         _lib.check(self._cid, _lib.lib().cid_timing_begin(self._cid, int(max_forwards)))
@@ -199,12 +213,14 @@ class DenoiseGenerator(nn.Module):
         return list(ms), n.value
 
 
-def launch_table(n: int, h: int, w: int):
-    """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes)] of one forward."""
+def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
+    """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes)] of one forward
+    (kernel symbols under `model`'s conv algorithm; direct kernels if no model is given)."""
     L = _lib.lib()
     rows = []
+    handle = model._cid if model is not None else None
     for i in range(_lib.CID_NUM_LAUNCHES):
         f, b = ctypes.c_double(), ctypes.c_double()
         _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f), ctypes.byref(b)))
-        rows.append((L.cid_launch_name(i).decode(), L.cid_launch_kernel(i).decode(), f.value, b.value))
+        rows.append((L.cid_launch_name(i).decode(), L.cid_launch_kernel(handle, i).decode(), f.value, b.value))
     return rows

@@ -130,8 +130,20 @@ int cid_timing_end(cid_handle_t h, void* stream, float* launch_ms_sum, int* forw
 
 /* Name of the i-th launch ("down1.0", ..., "upconv1.2"), the reference layer(s) it computes. */
 const char* cid_launch_name(int i);
-/* Device kernel symbol substring of the i-th launch (to match rocprofv3 kernel-trace rows). */
-const char* cid_launch_kernel(int i);
+/* Device kernel symbol prefix of the i-th launch under the handle's current algorithm (to match
+ * rocprofv3 kernel-trace rows). */
+const char* cid_launch_kernel(cid_handle_t h, int i);
+
+/*
+ * Algorithm of the eight GEMM-shaped 3x3 convolutions (down1[2] ... upconv1[0]); head, tail and the
+ * transposed convolutions are unaffected.  Both compute the reference's nn.Conv2d(k=3,p=1) in fp32:
+ *   CID_ALGO_DIRECT   implicit GEMM, 9 taps (36 multiplies per 2x2 outputs and (ci,co))
+ *   CID_ALGO_WINOGRAD Winograd F(2x2,3x3) (16 multiplies), the default
+ * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
+ */
+enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD = 1 };
+int cid_set_conv_algo(cid_handle_t h, int algo);
+int cid_get_conv_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);

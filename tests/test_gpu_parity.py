@@ -27,12 +27,20 @@ def _need_gpu():
         pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
 
 
-@pytest.fixture(scope="module")
-def models(weight_sets):
+@pytest.fixture(scope="module", params=["winograd", "direct"])
+def models(request, weight_sets):
+    """Both algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(2x2,3x3)
+    (the default) and the 9-tap implicit GEMM."""
     _need_gpu()
     import celebrity_image_denoiser_amd as cid
 
-    return {k: cid.load(v, device="cuda:0", strict=True) for k, v in weight_sets.items()}
+    out = {}
+    for k, v in weight_sets.items():
+        m = cid.load(v, device="cuda:0", strict=True)
+        m.conv_algo = request.param
+        assert m.conv_algo == request.param
+        out[k] = m
+    return out
 
 
 def _run(model, x):
@@ -151,6 +159,7 @@ def test_state_dict_reload_repacks(models, weight_sets):
 
     x, _, _ = synth.make_batch(1, 16, 16)
     m = cid.load(weight_sets["default"], device="cuda:0")
+    m.conv_algo = models["hot"].conv_algo
     y0 = _run(m, x)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}, strict=True)
     y1 = _run(m, x)
@@ -169,6 +178,20 @@ def test_iterated_denoise_and_host_roundtrip(models):
     assert torch.equal(y3, z.cpu())
     y_split = cid.denoise(models["hot"], x, max_batch=2)
     assert torch.equal(y_split, cid.denoise(models["hot"], x))
+
+
+def test_winograd_and_direct_agree(weight_sets):
+    """The two algorithms are independent fp32 evaluations of the same convolutions."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    x, _, _ = synth.make_batch(4, 128, 128, first_index=1300)
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    assert m.conv_algo == "winograd"
+    yw = _run(m, x)
+    m.conv_algo = "direct"
+    yd = _run(m, x)
+    assert np.abs(yw - yd).max() <= TOL and not np.array_equal(yw, yd)
 
 
 def test_native_library_is_loaded(models):
