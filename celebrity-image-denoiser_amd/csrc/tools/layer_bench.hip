@@ -3,6 +3,7 @@
 // Each variant is run ROUNDS times, interleaved with the others in one process; prints median ms
 // and algorithmic TFLOP/s.  ABLATE variants compute wrong results by design (see conv_kernels.h).
 #include "../conv_kernels.h"
+#include "../wino_kernels.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,19 @@ static Variant make(const char* name, int N, int H, int W, float* in, float* w, 
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_gemm_conv<CIN, COUT, MODE, ABLATE, WPS>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
 }
 
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
+static Variant makew(const char* name, int N, int H, int W, float* in, float* u, float* bias, float* out, float* pool) {
+    WinoArgs a{};
+    a.in = in; a.u = u; a.bias = bias; a.out = out; a.pool = pool;
+    a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
+    constexpr int BTR = 2 * (32 / TC);
+    a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);
+    a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    const int grid = 8 * a.tiles_per_xcd * (COUT / WN);
+    const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;   // algorithmic (direct) FLOPs
+    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? std::atoi(argv[1]) : 256;
     const int ROUNDS = 7;
@@ -52,17 +66,21 @@ int main(int argc, char** argv) {
     float* bB = dalloc(256, 0.1f);
     float* outB = dalloc((size_t)N * 32 * 32 * 256, 0.f);
     std::vector<Variant> v;
-    v.push_back(make<128, 64, 0, 0, 2>("A 128->64@128  base wps2", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 0, 3>("A 128->64@128  base wps3", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 1, 2>("A no-halo-prefetch", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 2, 2>("A no-B-loads", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 4, 2>("A no-A-reads", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 8, 2>("A no-stores", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 7, 2>("A mfma+stores", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<128, 64, 0, 15, 2>("A mfma-only", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(make<256, 256, 0, 0, 2>("B 256->256@32  base wps2", N, 32, 32, inB, wB, bB, outB, nullptr));
-    v.push_back(make<256, 256, 0, 15, 2>("B mfma-only", N, 32, 32, inB, wB, bB, outB, nullptr));
-    v.push_back(make<128, 64, 1, 0, 2>("A' pool 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
+    float* uA = dalloc((size_t)128 * 64 * 16, 0.05f);
+    float* uB = dalloc((size_t)256 * 256 * 16, 0.05f);
+    v.push_back(make<128, 64, 0, 0, 2>("A direct 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 0>("A wino base", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 1>("A wino no-halo-prefetch", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 2>("A wino no-B-loads", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 4>("A wino no-A-build", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 16>("A wino A-read-no-xform", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 8>("A wino no-epilogue", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 7>("A wino mfma+epilogue", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 15>("A wino mfma-only", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(make<256, 256, 0, 0, 2>("B direct 256->256@32", N, 32, 32, inB, wB, bB, outB, nullptr));
+    v.push_back(makew<256, 256, false, 16, 0>("B wino base", N, 32, 32, inB, uB, bB, outB, nullptr));
+    v.push_back(makew<256, 256, false, 16, 2>("B wino no-B-loads", N, 32, 32, inB, uB, bB, outB, nullptr));
+    v.push_back(makew<256, 256, false, 16, 15>("B wino mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
     std::vector<std::vector<float>> ms(v.size());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& x : v) x.run(s);   // warm-up
@@ -76,7 +94,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < v.size(); ++i) {
         std::sort(ms[i].begin(), ms[i].end());
         const float med = ms[i][ms[i].size() / 2];
-        std::printf("%-28s median %8.4f ms  min %8.4f ms  %7.2f TFLOP/s  (%.1f%% of 157.3)\n", v[i].name.c_str(), med, ms[i][0],
+        std::printf("%-28s median %8.4f ms  min %8.4f ms  %7.2f TFLOP/s  (%.1f%% of 157.3 algorithmic)\n", v[i].name.c_str(), med, ms[i][0],
                     v[i].flops / (med * 1e-3) / 1e12, 100.0 * v[i].flops / (med * 1e-3) / 1e12 / 157.3);
     }
     return 0;

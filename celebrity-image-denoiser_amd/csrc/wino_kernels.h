@@ -43,7 +43,10 @@ struct WinoArgs {
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
 };
 
-template <int CIN, int COUT, bool POOL, int TC>
+// ABLATE (timing experiments only, csrc/tools/layer_bench.hip; results are wrong when non-zero):
+//   bit 0: no halo prefetch after chunk 0   bit 1: B fragments loaded once   bit 2: A operand built once
+//   bit 3: no epilogue                      bit 4: A operand read from LDS but not transformed
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     constexpr int TRP = 32 / TC;                 // tile rows per pair
     constexpr int BTR = 2 * TRP;                 // tile rows per workgroup
@@ -138,16 +141,20 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
 
     auto chunk = [&](auto more_tag, int ck) {
         constexpr bool MORE = decltype(more_tag)::value;   // another chunk follows: prefetch it
-        const int cur = (ck & 1) * BUF;
+        constexpr bool PREF = MORE && !(ABLATE & 1);
+        const int cur = (ABLATE & 1) ? 0 : (ck & 1) * BUF;
         f32x4 hp[3];
+        f32x4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                      // unit k = (round g2 = k>>1, row u = k&1)
             const int g2 = k >> 1, u = k & 1;
             // next unit's B fragments
-            if (k < 3) load_b(bq[(k + 1) & 1], k + 1, ck);
-            else if (MORE) load_b(bq[0], 0, ck + 1);
+            if (!(ABLATE & 2)) {
+                if (k < 3) load_b(bq[(k + 1) & 1], k + 1, ck);
+                else if (MORE) load_b(bq[0], 0, ck + 1);
+            }
             // halo pieces of the next chunk: units 0,1,2 each issue up to 3 and write the previous unit's
-            if (MORE) {
+            if (PREF) {
                 if (k >= 1) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
@@ -162,27 +169,34 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
             // A operand: V[a][0..3] for 4 channels, rebuilt from rows x,y of the raw patch
             const int xb = (u ? xb1 : xb0) + 2 * g2, yb = (u ? yb1 : yb0) + 2 * g2;
             const float sg = u ? sgn1 : sgn0;
-            f32x4 t[4];
+            if (!(ABLATE & 4) || (k == 0 && ck == 0)) {
+                f32x4 t[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 xv = lds[cur + xb + c * WPS];
-                const f32x4 yv = lds[cur + yb + c * WPS];
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 xv = lds[cur + xb + c * WPS];
+                    const f32x4 yv = lds[cur + yb + c * WPS];
+                    if (ABLATE & 16) { t[c] = xv; t[c][0] += yv[1]; continue; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sg, yv[e], xv[e]);
+                    for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sg, yv[e], xv[e]);
+                }
+                if (ABLATE & 16) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = t[c];
+                } else {
+                    v[0] = t[0] - t[2];
+                    v[1] = t[1] + t[2];
+                    v[2] = t[2] - t[1];
+                    v[3] = t[1] - t[3];
+                }
             }
-            f32x4 v[4];
-            v[0] = t[0] - t[2];
-            v[1] = t[1] + t[2];
-            v[2] = t[2] - t[1];
-            v[3] = t[1] - t[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][e], bq[k & 1][b][e], acc[u][b], 0, 0, 0);
+                    acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][b][e], acc[u][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (MORE) __syncthreads();   // next buffer is complete, and everybody is done reading this one
+        if (PREF) __syncthreads();   // next buffer is complete, and everybody is done reading this one
     };
     for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
     chunk(std::false_type{}, NCHUNK - 1);
@@ -190,6 +204,17 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     // ---- output transform.  m'[u][b'] = sum_b M[a][b] A[b][b'] for the two rows of this wave ----
     // A^T = [[1,1,1,0],[0,1,-1,-1]]; partial P[a'][b'] = sum over own rows a of A^T[a'][a] m'[a][b']
     //   half 0 (a=0,1): P[0] = m'0 + m'1, P[1] = m'1        half 1 (a=2,3): P[0] = m'0, P[1] = -m'0 - m'1
+    if (ABLATE & 8) {   // keep the accumulators alive without the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[u][b][r];
+        if (sum == 123.456f) a.out[tid] = sum;
+        return;
+    }
     const float c01 = half ? 0.f : 1.f, c10 = half ? -1.f : 0.f, c11 = half ? -1.f : 1.f;
     __syncthreads();                                    // raw tiles are dead: LDS becomes exchange + staging
     f32x4* ex = lds + wave * (16 * 64);
