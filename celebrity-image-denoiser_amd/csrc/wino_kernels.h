@@ -104,7 +104,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
         okmask |= (ok ? 1u : 0u) << it;
     }
     const int wslot = (tid >> 2) * WPS + (tid & 3);   // piece `it` lands at wslot + it*64*WPS
-    auto halo_load = [&](int it, int ck) -> f32x4 { return *reinterpret_cast<const f32x4*>(inb + goff[it] + ck * WK); };
+    auto halo_load = [&](int it, int ck) -> f32x4 {
+        const float* cb = inb + ck * WK;                   // wave-uniform
+        return *reinterpret_cast<const f32x4*>(cb + goff[it]);
+    };
     auto halo_store = [&](int buf, int it, f32x4 v) {
         if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the convolution
         if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[buf * BUF + wslot + it * 64 * WPS] = v;
@@ -119,12 +122,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
             for (int r = 0; r < 16; ++r) acc[u][b][r] = 0.f;
 
     // U stream of this wave: unit (ck, g2, u) is 4 quads of 1 KiB at ((ck*2+g2)*4 + 2*half+u)*4*64 f32x4
-    const f32x4* up = reinterpret_cast<const f32x4*>(a.u) + ((size_t)nb * NCHUNK * 2 * 16 + 2 * half * 4) * 64 + lane;
+    // (wave-uniform base in SGPRs + the lane index as a 32-bit offset: no 64-bit VALU address arithmetic)
+    const f32x4* up = reinterpret_cast<const f32x4*>(a.u) + ((size_t)nb * NCHUNK * 2 * 16 + 2 * half * 4) * 64;
     auto load_b = [&](f32x4 (&dst)[4], int unit_in_chunk, int ck) {   // unit_in_chunk = g2*2 + u
         const int g2 = unit_in_chunk >> 1, u = unit_in_chunk & 1;
         const f32x4* q = up + ((size_t)((ck * 2 + g2) * 4 + u) * 4) * 64;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) dst[b] = q[b * 64];
+        for (int b = 0; b < 4; ++b) dst[b] = q[b * 64 + lane];
     };
 
     // ---- prologue: chunk 0 -> LDS buffer 0, first B unit ----
