@@ -52,7 +52,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], raw_w_off[NL], raw_b_off[NL], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -67,6 +67,7 @@ struct BlobLayout {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
             raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
+        zeros_off = o; o += 1024;   // 4 KiB zero page: source of LDS-DMA lanes that must deliver 0 (never written)
         total = o;
     }
 };
@@ -107,7 +108,8 @@ size_t ref_index(const LayerDef& L, int co, int ci, int kh, int kw) {
 
 // Winograd F(2x2,3x3) filter transform U = G g G^T (reference Conv2d weight [Cout,Cin,3,3] -> 16 values per
 // (co, ci)), in double, rounded once to fp32, laid out for wino_kernels.h:
-//   [nb = co/32][chunk = ci/16][round = (ci/8)%2][a][b][lane = 32*h + j][e],  ci = 16*chunk + 8*round + 4*h + e, co = 32*nb + j
+//   [nb = co/32][chunk = ci/16][round = (ci/8)%2][a][e][lane = 32*h + j][b],  ci = 16*chunk + 8*round + 4*h + e, co = 32*nb + j
+// (one 16-byte quad per lane = the four positions b of k-step e, so a quad's registers free up after 4 MFMAs)
 void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = L.cin / 16;
@@ -121,7 +123,7 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
             for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 4; ++b) {
                     const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
-                    dst[((((((size_t)nb * nchunk + ck) * 2 + g2) * 4 + a) * 4 + b) * 64 + h * 32 + j) * 4 + e] = (float)u;
+                    dst[((((((size_t)nb * nchunk + ck) * 2 + g2) * 4 + a) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
                 }
         }
 }
@@ -232,7 +234,8 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
                           float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
     if (algo == 0) return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
     WinoArgs a;
-    a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.out = out; a.pool = pool;
+    a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.zeros = blob + kBlob.zeros_off;
+    a.out = out; a.pool = pool;
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;

@@ -42,6 +42,8 @@ template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
 static Variant makew(const char* name, int N, int H, int W, float* in, float* u, float* bias, float* out, float* pool) {
     WinoArgs a{};
     a.in = in; a.u = u; a.bias = bias; a.out = out; a.pool = pool;
+    static float* zeros = dalloc(1024, 0.f);
+    a.zeros = zeros;
     a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
     constexpr int BTR = 2 * (32 / TC);
     a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);

@@ -16,9 +16,10 @@
 //     2*half+1}, i.e. 8 accumulator tiles = 128 VGPRs, and runs units of 16 MFMAs
 //     (one row a, 8 input channels: 4 positions b x 4 k-steps);
 //   * K is walked in 16-channel chunks through a double-buffered raw halo tile in LDS
-//     (pixel = 4 data slots + 1 pad slot of 16 B); the next chunk is fetched global -> registers ->
-//     LDS under the current chunk's MFMAs, ONE barrier per chunk;
-//   * B fragments (U, pre-packed per lane) stream L2 -> registers one unit ahead;
+//     (pixel = 4 data slots + 1 pad slot of 16 B); the next chunk is written by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPRs, no ds_write; out-of-image and pad slots read a zero page)
+//     under the current chunk's MFMAs, ONE barrier per chunk;
+//   * B fragments (U, pre-packed per lane) stream L2 -> registers two units ahead;
 //   * epilogue: the halves exchange their partial output transforms through LDS, then half h writes
 //     output row 2*tile_row + h (and half 0 the pooled row): bias, ReLU, 16-byte stores via LDS.
 #pragma once
@@ -33,8 +34,9 @@ constexpr int WS32 = 36;      // staging row stride (floats) for 32-channel slab
 
 struct WinoArgs {
     const float* in;    // NHWC [N, Hin, Win, in_ps]
-    const float* u;     // packed U: [nb][chunk][round][a][b][lane][4]
+    const float* u;     // packed U: [nb][chunk][round][a][e][lane][b]  (cid_api.hip pack_winograd_u)
     const float* bias;  // [COUT]
+    const float* zeros; // >= 4 KiB of zeros: source of every LDS-DMA lane that must deliver 0
     float* out;         // [N, Hs, Ws, out_ps] (+ out_coff)
     float* pool;        // POOL: [N, Hc/2, Wc/2, COUT]
     int N, Hin, Win, in_ps;
@@ -51,13 +53,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     constexpr int TRP = 32 / TC;                 // tile rows per pair
     constexpr int BTR = 2 * TRP;                 // tile rows per workgroup
     constexpr int LW = 2 * TC + 2, LH = 2 * BTR + 2, LPIX = LW * LH;
-    constexpr int NSLOT = LPIX * 4;
-    constexpr int NPIECE = (NSLOT + THREADS - 1) / THREADS;
-    constexpr int BUF = LPIX * WPS;              // f32x4 slots per LDS buffer
+    constexpr int NROUND = (LPIX * WPS + 63) / 64;   // LDS-DMA wave-instructions (64 slots of 16 B) per buffer
+    constexpr int RW = (NROUND + 3) / 4;             // rounds per wave
+    constexpr int BUF = NROUND * 64;                 // f32x4 slots per LDS buffer (padded to whole rounds)
     constexpr int NCHUNK = CIN / WK;
     constexpr int NB = COUT / WN;
     static_assert(CIN % WK == 0 && COUT % WN == 0 && (TC == 16 || TC == 32), "layer dims");
-    static_assert(NPIECE <= 8, "halo pieces are spread over the first three units of a chunk");
+    static_assert(RW <= 8 && CIN * 4 <= 4096, "DMA rounds per wave / zero page size");
 
     constexpr int EXCH = 4 * 16 * 64;            // epilogue exchange area: 4 waves x 16 registers x 64 lanes (f32x4)
     constexpr int LDS_SLOTS = (2 * BUF > EXCH) ? 2 * BUF : EXCH;
@@ -89,28 +91,31 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     const int xb0 = (pbase + xrow0 * LW) * WPS + h, yb0 = (pbase + yrow0 * LW) * WPS + h;
     const int xb1 = (pbase + xrow1 * LW) * WPS + h, yb1 = (pbase + yrow1 * LW) * WPS + h;
 
-    // ---- halo pieces of this thread: piece `it` is data slot s = it*256 + tid of the raw tile ----
+    // ---- LDS-DMA sources.  Round j of a buffer fills slots [64j, 64j+64); wave w issues rounds w, w+4, ...
+    // Lane l of round j owns slot s = 64j + l = pixel s/5, 16-byte group s%5 (group 4 = pad).  Its source is
+    // the pixel's 4 channels of the current chunk, or the zero page (padding of the convolution, pad slots,
+    // slots past the tile); both advance by 64 bytes per chunk, so one 64-bit add per round per chunk.
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    int goff[NPIECE];
-    unsigned okmask = 0;
+    const float* ga[RW];
 #pragma unroll
-    for (int it = 0; it < NPIECE; ++it) {
-        const int s = it * THREADS + tid;
-        const int p = s >> 2, c = s & 3;
+    for (int m = 0; m < RW; ++m) {
+        const int s = (wave + 4 * m) * 64 + lane;
+        const int p = s / WPS, c = s - p * WPS;
         const int hy = p / LW, hx = p - hy * LW;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        goff[it] = ok ? ((gy * a.Win + gx) * a.in_ps + c * 4) : 0;
-        okmask |= (ok ? 1u : 0u) << it;
+        const bool ok = c < 4 && p < LPIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        ga[m] = ok ? inb + ((gy * a.Win + gx) * a.in_ps + c * 4) : a.zeros;
     }
-    const int wslot = (tid >> 2) * WPS + (tid & 3);   // piece `it` lands at wslot + it*64*WPS
-    auto halo_load = [&](int it, int ck) -> f32x4 {
-        const float* cb = inb + ck * WK;                   // wave-uniform
-        return *reinterpret_cast<const f32x4*>(cb + goff[it]);
-    };
-    auto halo_store = [&](int buf, int it, f32x4 v) {
-        if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the convolution
-        if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[buf * BUF + wslot + it * 64 * WPS] = v;
+    const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
+    auto dma_rounds = [&](int buf, int m0, int m1) {   // issue rounds [m0, m1) of this wave into buffer `buf`, advance sources
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+            if (wave + 4 * m < NROUND) {               // wave-uniform
+                const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ga[m]), "s"(dst) : "memory");
+            }
+            ga[m] += WK;
+        }
     };
 
     f32x16 acc[2][4];
@@ -121,86 +126,112 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][b][r] = 0.f;
 
-    // U stream of this wave: unit (ck, g2, u) is 4 quads of 1 KiB at ((ck*2+g2)*4 + 2*half+u)*4*64 f32x4
-    // (wave-uniform base in SGPRs + the lane index as a 32-bit offset: no 64-bit VALU address arithmetic)
-    const f32x4* up = reinterpret_cast<const f32x4*>(a.u) + ((size_t)nb * NCHUNK * 2 * 16 + 2 * half * 4) * 64;
-    auto load_b = [&](f32x4 (&dst)[4], int unit_in_chunk, int ck) {   // unit_in_chunk = g2*2 + u
-        const int g2 = unit_in_chunk >> 1, u = unit_in_chunk & 1;
-        const f32x4* q = up + ((size_t)((ck * 2 + g2) * 4 + u) * 4) * 64;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dst[b] = q[b * 64 + lane];
+    // U stream of this wave: unit (ck, g2, u) is 4 quads of 1 KiB at ((ck*2+g2)*4 + 2*half+u)*4*64 f32x4; quad e
+    // holds, for k-step e, the four positions b:  [nb][chunk][round][a][e][lane][b].
+    const f32x4* up = reinterpret_cast<const f32x4*>(a.u) + ((size_t)nb * NCHUNK * 2 * 16 + 2 * half * 4) * 64 + lane;
+    auto b_ptr = [&](int gunit) -> const f32x4* {          // gunit = ck*4 + g2*2 + u, this wave's unit counter
+        return up + ((size_t)((gunit >> 1) * 4 + (gunit & 1)) * 4) * 64;
     };
 
-    // ---- prologue: chunk 0 -> LDS buffer 0, first B unit ----
-    {
-        f32x4 pre[NPIECE];
+    // ---- prologue: chunk 0 -> LDS buffer 0 by DMA; B of units 0 and 1 ----
+    if (!(ABLATE & 32)) dma_rounds(0, 0, RW);
+    f32x4 bq[2][4];                                        // ring: unit k uses bq[k&1][e]
 #pragma unroll
-        for (int it = 0; it < NPIECE; ++it) pre[it] = halo_load(it, 0);
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int it = 0; it < NPIECE; ++it) halo_store(0, it, pre[it]);
-    }
-    f32x4 bq[2][4];
-    load_b(bq[0], 0, 0);
+        for (int e = 0; e < 4; ++e) bq[d][e] = b_ptr(d)[e * 64];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to hipcc's own wait counting
     __syncthreads();
 
-    auto chunk = [&](auto more_tag, int ck) {
-        constexpr bool MORE = decltype(more_tag)::value;   // another chunk follows: prefetch it
-        constexpr bool PREF = MORE && !(ABLATE & 1);
+    // A operand of one unit (row a = 2*half+u of B^T d B, 4 channels): eight 16-byte reads of the raw
+    // patch, t = x + sgn*y per column (two columns at a time, to keep few reads in flight), then the four
+    // column combinations.
+    auto read_cols = [&](f32x4 (&xq)[2], f32x4 (&yq)[2], int bufbase, int k, int c0) {
+        const int g2 = k >> 1, u = k & 1;
+        const int xb = bufbase + (u ? xb1 : xb0) + 2 * g2, yb = bufbase + (u ? yb1 : yb0) + 2 * g2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            xq[c] = lds[xb + (c0 + c) * WPS];
+            yq[c] = lds[yb + (c0 + c) * WPS];
+        }
+    };
+    auto make_t = [&](f32x4 (&t)[4], const f32x4 (&xq)[2], const f32x4 (&yq)[2], int k, int c0) {
+        const float sg = (k & 1) ? sgn1 : sgn0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (ABLATE & 16) { t[c0 + c] = xq[c]; t[c0 + c][0] += yq[c][1]; continue; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c0 + c][e] = __builtin_fmaf(sg, yq[c][e], xq[c][e]);
+        }
+    };
+    auto make_v = [&](f32x4 (&v)[4], const f32x4 (&t)[4]) {
+        if (ABLATE & 16) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = t[c];
+        } else {
+            v[0] = t[0] - t[2];
+            v[1] = t[1] + t[2];
+            v[2] = t[2] - t[1];
+            v[3] = t[1] - t[3];
+        }
+    };
+
+    f32x4 vcur[4], vnxt[4];
+    {
+        f32x4 xq[2], yq[2], t[4];
+        read_cols(xq, yq, 0, 0, 0);
+        make_t(t, xq, yq, 0, 0);
+        read_cols(xq, yq, 0, 0, 2);
+        make_t(t, xq, yq, 0, 2);
+        make_v(vcur, t);
+    }
+
+    // Chunk ck (LDS buffer ck&1).  Unit k runs 16 MFMAs (k-step e outer, position b inner: four independent
+    // accumulators in rotation) and, under them:
+    //   * reads and builds the A operand of the NEXT unit (unit 3: unit 0 of the next chunk, other buffer);
+    //   * refills B quad e, two units ahead, as soon as the four MFMAs of k-step e have issued;
+    //   * units 0 and 1 start the LDS-DMA of the next chunk into the other buffer (free since the previous
+    //     barrier).  vmcnt retires in order: the only loads queued behind a DMA are B refills that are not
+    //     consumed until two units later.
+    // One barrier, at the end of unit 2, behind `s_waitcnt vmcnt(8)`: the eight B refills of units 1 and 2 are
+    // the only vector-memory operations younger than the last DMA, so at most 8 outstanding means every DMA
+    // of this wave has landed; past the barrier every wave's has, and nobody reads this buffer again.
+    auto chunk = [&](auto has_next_tag, int ck) {
+        constexpr bool NEXT = decltype(has_next_tag)::value && !(ABLATE & 1);
         const int cur = (ABLATE & 1) ? 0 : (ck & 1) * BUF;
-        f32x4 hp[3];
-        f32x4 v[4];
+        const int nxt = (ABLATE & 1) ? 0 : BUF - cur;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                      // unit k = (round g2 = k>>1, row u = k&1)
-            const int g2 = k >> 1, u = k & 1;
-            // next unit's B fragments
-            if (!(ABLATE & 2)) {
-                if (k < 3) load_b(bq[(k + 1) & 1], k + 1, ck);
-                else if (MORE) load_b(bq[0], 0, ck + 1);
-            }
-            // halo pieces of the next chunk: units 0,1,2 each issue up to 3 and write the previous unit's
-            if (PREF) {
-                if (k >= 1) {
+        for (int k = 0; k < 4; ++k) {
+            const int u = k & 1;
+            const bool have_next_unit = ((k < 3) || decltype(has_next_tag)::value) && !(ABLATE & 4);
+            const int nbuf = (k < 3) ? cur : nxt, nk = (k + 1) & 3;
+            f32x4 xq[2], yq[2], t[4];
+            if (NEXT && k == 0) dma_rounds((ck + 1) & 1, 0, RW / 2);
+            if (NEXT && k == 1) dma_rounds((ck + 1) & 1, RW / 2, RW);
+            if (have_next_unit) read_cols(xq, yq, nbuf, nk, 0);
+            const bool refill = !(ABLATE & 2) && ((k < 2) || decltype(has_next_tag)::value);
+            const f32x4* bp = b_ptr(ck * 4 + k + 2);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if ((k - 1) * 3 + j < NPIECE) halo_store(((ck + 1) & 1), (k - 1) * 3 + j, hp[j]);
-                }
-                if (k < 3) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (k * 3 + j < NPIECE) hp[j] = halo_load(k * 3 + j, ck + 1);
-                }
-            }
-            // A operand: V[a][0..3] for 4 channels, rebuilt from rows x,y of the raw patch
-            const int xb = (u ? xb1 : xb0) + 2 * g2, yb = (u ? yb1 : yb0) + 2 * g2;
-            const float sg = u ? sgn1 : sgn0;
-            if (!(ABLATE & 4) || (k == 0 && ck == 0)) {
-                f32x4 t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 xv = lds[cur + xb + c * WPS];
-                    const f32x4 yv = lds[cur + yb + c * WPS];
-                    if (ABLATE & 16) { t[c] = xv; t[c][0] += yv[1]; continue; }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sg, yv[e], xv[e]);
-                }
-                if (ABLATE & 16) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = t[c];
-                } else {
-                    v[0] = t[0] - t[2];
-                    v[1] = t[1] + t[2];
-                    v[2] = t[2] - t[1];
-                    v[3] = t[1] - t[3];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][b][e], acc[u][b], 0, 0, 0);
+                    acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][e][b], acc[u][b], 0, 0, 0);
+                if (refill) bq[k & 1][e] = bp[e * 64];
+                if (have_next_unit) {
+                    if (e == 0) { make_t(t, xq, yq, nk, 0); read_cols(xq, yq, nbuf, nk, 2); }
+                    if (e == 1) { make_t(t, xq, yq, nk, 2); make_v(vnxt, t); }
+                }
+            }
+            if (have_next_unit) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vcur[b] = vnxt[b];
+            }
+            if (NEXT && k == 2) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __syncthreads();
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (PREF) __syncthreads();   // next buffer is complete, and everybody is done reading this one
     };
     for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
     chunk(std::false_type{}, NCHUNK - 1);
