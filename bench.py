@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--algo", default="winograd", choices=["winograd", "direct"],
                     help="algorithm of the eight 3x3 GEMM layers (both fp32; default Winograd F(2x2,3x3))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,8 +111,10 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, S = args.batch_per_gpu, args.size
@@ -118,7 +122,7 @@ def main():
     # rank 0 owns the checkpoint; everyone else starts from its own random init and receives the blob
     model = cid.load(sd if rank == 0 else None, device=dev, strict=True)
     model.conv_algo = args.algo
-    if world > 1:
+    if use_dist:
         cdist.broadcast_weights(model, src=0)
 
     begin, end = cdist.shard_range(B * world, rank, world)
@@ -127,7 +131,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     y = None
@@ -146,7 +150,7 @@ def main():
     launch_ms, nfw = model.timing_end()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -229,7 +233,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

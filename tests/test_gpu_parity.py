@@ -194,6 +194,22 @@ def test_winograd_and_direct_agree(weight_sets):
     assert np.abs(yw - yd).max() <= TOL and not np.array_equal(yw, yd)
 
 
+def test_adopt_device_blob_like_a_broadcast_receiver(weight_sets):
+    """What a non-source rank does after the RCCL broadcast: attach a packed device blob produced by another
+    module, refresh the nn.Parameters from it, compute the same outputs."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    src = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    dst = cid.load(None, device="cuda:0")                      # random init, like a rank that read no checkpoint
+    blob = src.pack_weights().clone()
+    dst.adopt_packed_weights(blob, update_parameters=True)
+    assert all(torch.equal(dst.state_dict()[k].cpu(), torch.from_numpy(v)) for k, v in weight_sets["hot"].items())
+    x, _, _ = synth.make_batch(2, 32, 32, first_index=1400)
+    assert np.array_equal(_run(src, x), _run(dst, x))
+    assert np.array_equal(_run(dst, x), _run(dst, x))          # and the adopted blob is not repacked/invalidated
+
+
 def test_native_library_is_loaded(models):
     """The parity above ran through libcid.so, not through any PyTorch op."""
     from celebrity_image_denoiser_amd import _lib
