@@ -5,6 +5,7 @@ Public surface (mirrors what the reference's callers use, reference backend/app.
     DenoiseGenerator()            nn.Module-protocol object: .to(), .load_state_dict(), .eval(), __call__
     load(path_or_state_dict)      -> DenoiseGenerator on the current GPU, weights loaded like load_state_safely
     denoise(model, image_batch)   -> image_batch
+    denoise_u8(model, uint8 NHWC) -> uint8 NHWC (pre/post-processing fused into the first/last kernel)
 
 Everything numeric runs in hand-written HIP kernels behind the C ABI in include/cid.h
 (csrc/ -> libcid.so).  There is no CPU fallback: if the library is missing the calls raise.
@@ -15,6 +16,7 @@ _LAZY = {
     "DenoiseGenerator": ("generator", "DenoiseGenerator"),
     "load": ("api", "load"),
     "denoise": ("api", "denoise"),
+    "denoise_u8": ("api", "denoise_u8"),
     "load_state_safely": ("api", "load_state_safely"),
     "psnr": ("metrics", "psnr"),
 }

@@ -11,6 +11,7 @@ CID_OK = 0
 CID_NUM_PARAMS = 24
 CID_NUM_LAUNCHES = 12
 CID_ALGO_DIRECT, CID_ALGO_WINOGRAD = 0, 1
+CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
 
 # every symbol include/cid.h declares: (restype, argtypes)
 _c = ctypes
@@ -32,6 +33,8 @@ SYMBOLS = {
     "cid_workspace_bytes": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "cid_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "cid_forward_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                  _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "cid_forward_timed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_float)]),
     "cid_timing_begin": (_c.c_int, [_c.c_void_p, _c.c_int]),

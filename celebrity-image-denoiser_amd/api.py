@@ -88,6 +88,18 @@ def denoise(model: DenoiseGenerator, image_batch: torch.Tensor, iterations: int 
     return y.to(src_dev)
 
 
+def denoise_u8(model: DenoiseGenerator, images_u8: torch.Tensor, max_batch: Optional[int] = None) -> torch.Tensor:
+    """uint8 image batch [N,H,W,3] -> uint8 image batch [N,4*(H//4),4*(W//4),3]: the serving path of the
+    reference (decode -> ToTensor -> Normalize -> net -> y*0.5+0.5 -> clamp -> ToPILImage, app.py:400-406,433-435,
+    471-472) with everything between the two uint8 images on the GPU; 4x less PCIe traffic than fp32 tensors."""
+    dev = next(model.parameters()).device
+    src_dev = images_u8.device
+    step = max_batch or images_u8.shape[0]
+    outs = [model.forward_u8(images_u8[i:i + step].to(dev, non_blocking=True)) for i in range(0, images_u8.shape[0], step)]
+    y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+    return y.to(src_dev)
+
+
 def to_unit_range(y: torch.Tensor) -> torch.Tensor:
     """The reference's view transform for tanh-range outputs: y*0.5+0.5 clamped to [0,1] (app.py:435)."""
     return (y * 0.5 + 0.5).clamp(0, 1)

@@ -243,16 +243,18 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
 
-hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid) {
-    hipLaunchKernelGGL(k_conv_head, dim3(grid), dim3(THREADS), 0, s, a);
+hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8) {
+    if (u8) hipLaunchKernelGGL(k_conv_head<true>, dim3(grid), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_conv_head<false>, dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid) {
-    hipLaunchKernelGGL(k_conv_tail, dim3(grid), dim3(THREADS), 0, s, a);
+hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8) {
+    if (u8) hipLaunchKernelGGL(k_conv_tail<true>, dim3(grid), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_conv_tail<false>, dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 
-int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W, void* ws, size_t ws_bytes,
+int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W, void* ws, size_t ws_bytes,
                 hipStream_t s, hipEvent_t* ev /* NL+1 events or null */) {
     if (!h) return CID_ERR_INVALID;
     if (!in || !out || !ws) return fail(h, CID_ERR_INVALID, "cid_forward: null pointer");
@@ -265,8 +267,10 @@ int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W
     }
     const Plan p = make_plan(d);
     if (ws_bytes < p.total_bytes) return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace smaller than cid_workspace_bytes()");
-    if (((uintptr_t)ws & 255) || ((uintptr_t)in & 15) || ((uintptr_t)h->dev_blob & 255))
-        return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace/weights must be 256-byte aligned, input 16-byte aligned");
+    if ((in_fmt != CID_FMT_F32_NCHW && in_fmt != CID_FMT_U8_NHWC) || (out_fmt != CID_FMT_F32_NCHW && out_fmt != CID_FMT_U8_NHWC))
+        return fail(h, CID_ERR_INVALID, "cid_forward: unknown tensor format");
+    if (((uintptr_t)ws & 255) || ((uintptr_t)h->dev_blob & 255) || (in_fmt == CID_FMT_F32_NCHW && ((uintptr_t)in & 3)))
+        return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace/weights must be 256-byte aligned, fp32 input 4-byte aligned");
     float* base = static_cast<float*>(ws);
     float* B[NBUF];
     for (int b = 0; b < NBUF; ++b) B[b] = base + p.off[b];
@@ -289,7 +293,7 @@ int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
-        STEP(launch_head(s, a, 8 * g.per_xcd));
+        STEP(launch_head(s, a, 8 * g.per_xcd, in_fmt == CID_FMT_U8_NHWC));
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
     STEP((launch_conv3x3<64, 64, 1>(h->algo, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
@@ -315,7 +319,7 @@ int run_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
-        STEP(launch_tail(s, a, 8 * g.per_xcd));
+        STEP(launch_tail(s, a, 8 * g.per_xcd, out_fmt == CID_FMT_U8_NHWC));
     }
 #undef STEP
     if (ev && hipEventRecord(ev[NL], s) != hipSuccess) return fail(h, CID_ERR_HIP, "hipEventRecord failed");
@@ -457,9 +461,14 @@ int cid_workspace_bytes(int N, int H, int W, size_t* bytes) {
 }
 
 int cid_forward(cid_handle_t h, const float* in, float* out, int N, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    return cid_forward_ex(h, in, CID_FMT_F32_NCHW, out, CID_FMT_F32_NCHW, N, H, W, ws, ws_bytes, stream);
+}
+
+int cid_forward_ex(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W,
+                   void* ws, size_t ws_bytes, void* stream) {
     hipEvent_t* ev = nullptr;
     if (h && h->tev_used < h->tev_forwards) ev = h->tev.data() + (size_t)h->tev_used * (NL + 1);
-    const int rc = run_forward(h, in, out, N, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), ev);
+    const int rc = run_forward(h, in, in_fmt, out, out_fmt, N, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), ev);
     if (ev && rc == CID_OK) ++h->tev_used;
     return rc;
 }
@@ -511,7 +520,7 @@ int cid_forward_timed(cid_handle_t h, const float* in, float* out, int N, int H,
         if (hipEventCreate(&ev[made]) != hipSuccess) break;
     int rc = made == NL + 1 ? CID_OK : fail(h, CID_ERR_HIP, "hipEventCreate failed");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (rc == CID_OK) rc = run_forward(h, in, out, N, H, W, ws, ws_bytes, s, ev);
+    if (rc == CID_OK) rc = run_forward(h, in, CID_FMT_F32_NCHW, out, CID_FMT_F32_NCHW, N, H, W, ws, ws_bytes, s, ev);
     if (rc == CID_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(h, CID_ERR_HIP, "cid_forward_timed: stream sync failed");
     if (rc == CID_OK)
         for (int l = 0; l < NL; ++l)

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 // input directly (the NCHW -> NHWC change of layout is folded into this kernel), K = 27 padded
 // to 28 = 14 MFMA k-steps; memory-bound on its 64-channel NHWC output.
 struct HeadArgs {
-    const float* in;    // NCHW [N,3,H,W]
+    const void* in;     // fp32 NCHW [N,3,H,W], or (IN_U8) uint8 NHWC [N,H,W,3]
     const float* w;     // packed [2 ns][14 steps][64 lanes]
     const float* bias;  // [64]
     float* out;         // NHWC [N,H,W,64]
@@ -332,6 +332,9 @@ struct HeadArgs {
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
 };
 
+// IN_U8: the caller's image is uint8 HWC (what PIL hands the reference); ToTensor (/255) and Normalize(0.5,0.5)
+// (app.py:401-405) are applied on the fly, in fp32, with true divisions like torchvision: (u8/255 - 0.5)/0.5.
+template <bool IN_U8>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;   // 34 used columns, padded to 36
     __shared__ __attribute__((aligned(16))) float lds[4 * WS_FLOATS];   // input planes (3*PLANE floats), then store staging
@@ -348,8 +351,15 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
         const int c = s / (LH * 34), rem = s - c * (LH * 34);
         const int hy = rem / 34, hx = rem - hy * 34;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        float v = 0.f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.in[((size_t)(n * 3 + c) * a.H + gy) * a.W + gx];
+        float v = 0.f;   // zero padding applies to the NORMALISED tensor
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            if (IN_U8) {
+                const float t = (float)static_cast<const unsigned char*>(a.in)[((size_t)(n * a.H + gy) * a.W + gx) * 3 + c];
+                v = (t / 255.0f - 0.5f) / 0.5f;
+            } else {
+                v = static_cast<const float*>(a.in)[((size_t)(n * 3 + c) * a.H + gy) * a.W + gx];
+            }
+        }
         lds[c * PLANE + hy * LW + hx] = v;
     }
     float bw[2][14], bias_v[2];
@@ -411,11 +421,14 @@ struct TailArgs {
     const float* in;    // NHWC [N,H,W,64]
     const float* w;     // packed [2 chunk][4 group][64 lanes][4]  (cid_api.hip packed_index, TAIL)
     const float* bias;  // [3]
-    float* out;         // NCHW [N,3,H,W]
+    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
     int N, H, W;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
 };
 
+// OUT_U8: the reference's view transform and PIL conversion folded in: y*0.5+0.5, clamp to [0,1] (app.py:435),
+// then ToPILImage's mul(255).byte() — truncation, not rounding (app.py:471-472; denoisegan_eval.py:97-98).
+template <bool OUT_U8>
 __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;   // 340 halo pixels
     constexpr int MT = (LPIX + 31) / 32, LP = MT * 32;                // 11 M tiles, 352 rows
@@ -504,11 +517,20 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
     }
     const int y = y0 + row, x = x0 + col;
     if (y < a.H && x < a.W) {
-        const size_t plane = (size_t)a.H * a.W;
-        float* op = a.out + (size_t)n * 3 * plane + (size_t)y * a.W + x;
-        op[0] = tanhf(o[0]);
-        op[plane] = tanhf(o[1]);
-        op[2 * plane] = tanhf(o[2]);
+        if (OUT_U8) {
+            unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * 3;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
+                op[co] = (unsigned char)(v * 255.0f);
+            }
+        } else {
+            const size_t plane = (size_t)a.H * a.W;
+            float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+            op[0] = tanhf(o[0]);
+            op[plane] = tanhf(o[1]);
+            op[2 * plane] = tanhf(o[2]);
+        }
     }
 }
 

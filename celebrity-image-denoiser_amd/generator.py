@@ -173,6 +173,41 @@ class DenoiseGenerator(nn.Module):
                                                          self._ws.data_ptr(), self._ws.numel(), stream))
         return y
 
+    def forward_u8(self, images: torch.Tensor, out_u8: bool = True) -> torch.Tensor:
+        """uint8 images [N,H,W,3] (PIL/numpy layout) on the GPU -> denoised images, with the reference's
+        pre/post-processing folded into the first/last kernel (cid_forward_ex):
+        input  (u8/255 - 0.5)/0.5                       app.py:401-405 (ToTensor + Normalize(0.5, 0.5))
+        output (uint8)(clamp(y*0.5+0.5, 0, 1) * 255)    app.py:435, 471-472 (ToPILImage truncates)
+        Returns uint8 [N,4*(H//4),4*(W//4),3], or with out_u8=False the fp32 NCHW tensor `forward` returns."""
+        if not isinstance(images, torch.Tensor) or images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise RuntimeError("forward_u8 expects a uint8 tensor of shape [N,H,W,3]")
+        if images.device.type != "cuda":
+            raise RuntimeError("forward_u8 got a CPU tensor: this implementation is GPU-only; there is no CPU fallback")
+        if images.device != self._device():
+            raise RuntimeError(f"input on {images.device} but module parameters on {self._device()}")
+        n, h, w, _ = images.shape
+        L = _lib.lib()
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        if n < 1 or L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) != _lib.CID_OK:
+            raise RuntimeError(f"Given input size: ({h}x{w}). Calculated output size is too small (H and W must be >= 4)")
+        self.pack_weights()
+        need = ctypes.c_size_t()
+        _lib.check(self._cid, L.cid_workspace_bytes(n, h, w, ctypes.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != images.device:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=images.device)
+        images = images.contiguous()
+        if out_u8:
+            y = torch.empty((n, ho.value, wo.value, 3), dtype=torch.uint8, device=images.device)
+        else:
+            y = torch.empty((n, 3, ho.value, wo.value), dtype=torch.float32, device=images.device)
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        with torch.cuda.device(images.device):
+            _lib.check(self._cid, L.cid_forward_ex(self._cid, images.data_ptr(), _lib.CID_FMT_U8_NHWC, y.data_ptr(),
+                                                   _lib.CID_FMT_U8_NHWC if out_u8 else _lib.CID_FMT_F32_NCHW,
+                                                   n, h, w, self._ws.data_ptr(), self._ws.numel(), stream))
+        return y
+
     def forward_timed(self, x: torch.Tensor):
         """forward + per-launch milliseconds from HIP events on the launch stream (measurement aid)."""
         x, y, n, h, w = self._prepare(x)

@@ -111,6 +111,20 @@ int cid_forward(cid_handle_t h, const float* in_nchw, float* out_nchw, int N, in
                 void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The forward with the reference's pre/post-processing folded into the first and last kernel
+ * (SURVEY.md 8f row f1).  Formats:
+ *   CID_FMT_F32_NCHW  fp32 [N,3,H,W] — what cid_forward takes/returns
+ *   CID_FMT_U8_NHWC   uint8 [N,H,W,3], PIL/numpy image layout.  As input it is normalised on the fly,
+ *                     (u8/255 - 0.5)/0.5 in fp32 = ToTensor + Normalize(0.5,0.5), backend/app.py:401-405;
+ *                     as output it is (uint8)(clamp(y*0.5+0.5, 0, 1)*255), truncating like
+ *                     ToPILImage's mul(255).byte(), backend/app.py:435,471-472.
+ * Any combination is allowed; cid_forward == cid_forward_ex(F32_NCHW, F32_NCHW).
+ */
+enum { CID_FMT_F32_NCHW = 0, CID_FMT_U8_NHWC = 1 };
+int cid_forward_ex(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Same forward, with a HIP event recorded on `stream` around every kernel launch; synchronises
  * the stream and writes the CID_NUM_LAUNCHES per-launch durations in milliseconds to launch_ms.
  * Measurement aid for bench.py's roofline object; not part of the reference surface.

@@ -93,6 +93,17 @@ def main():
         r = run(model, x)
         np.savez_compressed(os.path.join(HERE, f"full_{wset}_128.npz"), out=r["out"],
                             x_sha256=np.frombuffer(hashlib.sha256(x.tobytes()).digest(), dtype=np.uint8))
+        # f1 row: uint8 HWC in -> uint8 HWC out through the reference's own pre/post arithmetic around the lifted
+        # module: ToTensor (/255) + Normalize(0.5,0.5) (app.py:401-405), y*0.5+0.5 clamp(0,1) (app.py:435),
+        # ToPILImage = mul(255).byte() (torchvision, truncating; app.py:471-472).  torchvision is not installed
+        # here, so these three third-party steps are written out with torch ops.
+        _, _, noisy_u8 = synth.make_batch(2, 32, 40, 60)
+        xt = torch.from_numpy(noisy_u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+        xt = (xt - 0.5) / 0.5
+        with torch.no_grad():
+            yt = model(xt)
+        y_u8 = (yt * 0.5 + 0.5).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).contiguous().numpy()
+        np.savez_compressed(os.path.join(HERE, f"u8_{wset}_32x40.npz"), noisy_u8=noisy_u8, out_u8=y_u8, out_f32=yt.numpy())
         for tag, (n, h, w, first) in {"n4_128": (4, 128, 128, 200), "n1_256": (1, 256, 256, 300)}.items():
             x, clean, _ = synth.make_batch(n, h, w, first)
             r = run(model, x)

@@ -216,3 +216,27 @@ def test_native_library_is_loaded(models):
 
     maps = open("/proc/self/maps").read()
     assert os.path.realpath(_lib.LIB_PATH) in maps
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_u8_in_u8_out_golden(models, golden_dir, wset):
+    """uint8 HWC image -> uint8 HWC image with the reference's pre/post-processing folded
+    into the first/last kernel, against the fixture made with the reference module (make_golden.py).
+    The fp32 tensor must agree to 1e-5; the uint8 image is a truncation of it, so a value within 1e-5*255 of an
+    integer may land one step away: allow |delta| <= 1 on at most 0.1 % of the bytes, 0 elsewhere."""
+    import celebrity_image_denoiser_amd as cid
+
+    g = np.load(os.path.join(golden_dir, f"u8_{wset}_32x40.npz"))
+    m = models[wset]
+    img = torch.from_numpy(g["noisy_u8"]).to("cuda:0")
+    y_f32 = m.forward_u8(img, out_u8=False).cpu().numpy()
+    assert np.abs(y_f32 - g["out_f32"]).max() <= TOL
+    y_u8 = m.forward_u8(img).cpu().numpy()
+    assert y_u8.shape == g["out_u8"].shape and y_u8.dtype == np.uint8
+    d = np.abs(y_u8.astype(np.int16) - g["out_u8"].astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+    # host convenience wrapper: host uint8 in -> host uint8 out, identical bytes
+    assert np.array_equal(cid.denoise_u8(m, torch.from_numpy(g["noisy_u8"])).numpy(), y_u8)
+    # fused normalisation == explicit normalisation followed by the fp32 forward, bit for bit
+    x = synth.normalize_u8(g["noisy_u8"])
+    assert np.array_equal(_run(m, x), y_f32)
