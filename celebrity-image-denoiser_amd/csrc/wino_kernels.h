@@ -87,9 +87,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     const int xrow0 = half ? 2 : 0, yrow0 = half ? 1 : 2;
     const int xrow1 = 1, yrow1 = half ? 3 : 2;
     const float sgn0 = -1.f, sgn1 = half ? -1.f : 1.f;
-    const int pbase = (2 * (pair * TRP + tr)) * LW + 2 * tc;
+    // LDS pixel order inside a tile row: even columns first, then odd columns (column hx at (hx&1)*LW/2 + hx/2).
+    // The 32 lanes of a read want columns 2*tc + c: with this order they are CONSECUTIVE pixels (stride 5 slots),
+    // which ds_read_b128 serves conflict-free; in natural order they are 2 pixels apart = a 2-way bank conflict.
+    constexpr int HWD = LW / 2;
+    const int pbase = (2 * (pair * TRP + tr)) * LW + tc;
     const int xb0 = (pbase + xrow0 * LW) * WPS + h, yb0 = (pbase + yrow0 * LW) * WPS + h;
     const int xb1 = (pbase + xrow1 * LW) * WPS + h, yb1 = (pbase + yrow1 * LW) * WPS + h;
+    auto col_off = [](int c) { return ((c & 1) * HWD + (c >> 1)) * WPS; };   // patch column c -> slot offset
 
     // ---- LDS-DMA sources.  Round j of a buffer fills slots [64j, 64j+64); wave w issues rounds w, w+4, ...
     // Lane l of round j owns slot s = 64j + l = pixel s/5, 16-byte group s%5 (group 4 = pad).  Its source is
@@ -101,7 +106,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     for (int m = 0; m < RW; ++m) {
         const int s = (wave + 4 * m) * 64 + lane;
         const int p = s / WPS, c = s - p * WPS;
-        const int hy = p / LW, hx = p - hy * LW;
+        const int hy = p / LW, rem = p - hy * LW;
+        const int plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;   // even/odd column planes (see above)
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = c < 4 && p < LPIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         ga[m] = ok ? inb + ((gy * a.Win + gx) * a.in_ps + c * 4) : a.zeros;
@@ -151,8 +157,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
         const int xb = bufbase + (u ? xb1 : xb0) + 2 * g2, yb = bufbase + (u ? yb1 : yb0) + 2 * g2;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            xq[c] = lds[xb + (c0 + c) * WPS];
-            yq[c] = lds[yb + (c0 + c) * WPS];
+            xq[c] = lds[xb + col_off(c0 + c)];
+            yq[c] = lds[yb + col_off(c0 + c)];
         }
     };
     auto make_t = [&](f32x4 (&t)[4], const f32x4 (&xq)[2], const f32x4 (&yq)[2], int k, int c0) {
@@ -252,34 +258,63 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     }
     const float c01 = half ? 0.f : 1.f, c10 = half ? -1.f : 0.f, c11 = half ? -1.f : 1.f;
     __syncthreads();                                    // raw tiles are dead: LDS becomes exchange + staging
-    f32x4* ex = lds + wave * (16 * 64);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float m00 = acc[0][0][r] + acc[0][1][r] + acc[0][2][r], m01 = acc[0][1][r] - acc[0][2][r] - acc[0][3][r];
-        const float m10 = acc[1][0][r] + acc[1][1][r] + acc[1][2][r], m11 = acc[1][1][r] - acc[1][2][r] - acc[1][3][r];
-        f32x4 p;
-        p[0] = __builtin_fmaf(c01, m10, m00);
-        p[1] = __builtin_fmaf(c01, m11, m01);
-        p[2] = c10 * m00 + c11 * m10;
-        p[3] = c10 * m01 + c11 * m11;
-        ex[r * 64 + lane] = p;
-        acc[0][0][r] = p[0]; acc[0][1][r] = p[1]; acc[0][2][r] = p[2]; acc[0][3][r] = p[3];
-    }
-    __syncthreads();
-    const f32x4* exo = lds + (wave ^ 1) * (16 * 64);
     float yrow[2][16];   // this wave's output row a' = half: columns b' = 0,1 of each tile
     float pooled[16];
+    if (POOL) {
+        // the pooled value needs all four outputs of a tile: exchange both rows of the partial transform
+        f32x4* ex = lds + wave * (16 * 64);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const f32x4 o = exo[r * 64 + lane];
-        // add in a fixed order (half 0's partial first) so both halves see bit-identical Y
-        const float y00 = half ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0];
-        const float y01 = half ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1];
-        const float y10 = half ? o[2] + acc[0][2][r] : acc[0][2][r] + o[2];
-        const float y11 = half ? o[3] + acc[0][3][r] : acc[0][3][r] + o[3];
-        yrow[0][r] = fmaxf((half ? y10 : y00) + bias_v, 0.f);
-        yrow[1][r] = fmaxf((half ? y11 : y01) + bias_v, 0.f);
-        if (POOL) pooled[r] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias_v, 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const float m00 = acc[0][0][r] + acc[0][1][r] + acc[0][2][r], m01 = acc[0][1][r] - acc[0][2][r] - acc[0][3][r];
+            const float m10 = acc[1][0][r] + acc[1][1][r] + acc[1][2][r], m11 = acc[1][1][r] - acc[1][2][r] - acc[1][3][r];
+            f32x4 p;
+            p[0] = __builtin_fmaf(c01, m10, m00);
+            p[1] = __builtin_fmaf(c01, m11, m01);
+            p[2] = c10 * m00 + c11 * m10;
+            p[3] = c10 * m01 + c11 * m11;
+            ex[r * 64 + lane] = p;
+            acc[0][0][r] = p[0]; acc[0][1][r] = p[1]; acc[0][2][r] = p[2]; acc[0][3][r] = p[3];
+        }
+        __syncthreads();
+        const f32x4* exo = lds + (wave ^ 1) * (16 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 o = exo[r * 64 + lane];
+            // add in a fixed order (half 0's partial first) so both halves see bit-identical Y
+            const float y00 = half ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0];
+            const float y01 = half ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1];
+            const float y10 = half ? o[2] + acc[0][2][r] : acc[0][2][r] + o[2];
+            const float y11 = half ? o[3] + acc[0][3][r] : acc[0][3][r] + o[3];
+            yrow[0][r] = fmaxf((half ? y10 : y00) + bias_v, 0.f);
+            yrow[1][r] = fmaxf((half ? y11 : y01) + bias_v, 0.f);
+            pooled[r] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias_v, 0.f);
+        }
+    } else {
+        // each half only needs the partner's partial of ITS output row: 8 bytes per value pair
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2* ex = reinterpret_cast<f32x2*>(lds) + wave * (16 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m00 = acc[0][0][r] + acc[0][1][r] + acc[0][2][r], m01 = acc[0][1][r] - acc[0][2][r] - acc[0][3][r];
+            const float m10 = acc[1][0][r] + acc[1][1][r] + acc[1][2][r], m11 = acc[1][1][r] - acc[1][2][r] - acc[1][3][r];
+            const float p00 = __builtin_fmaf(c01, m10, m00), p01 = __builtin_fmaf(c01, m11, m01);
+            const float p10 = c10 * m00 + c11 * m10, p11 = c10 * m01 + c11 * m11;
+            f32x2 give;                      // what the partner needs: half 0 gives row 1, half 1 gives row 0
+            give[0] = half ? p00 : p10;
+            give[1] = half ? p01 : p11;
+            ex[r * 64 + lane] = give;
+            acc[0][0][r] = half ? p10 : p00;  // what this wave keeps: its own output row
+            acc[0][1][r] = half ? p11 : p01;
+        }
+        __syncthreads();
+        const f32x2* exo = reinterpret_cast<const f32x2*>(lds) + (wave ^ 1) * (16 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x2 o = exo[r * 64 + lane];
+            // fixed order (half 0's partial first), as in the POOL path
+            yrow[0][r] = fmaxf((half ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0]) + bias_v, 0.f);
+            yrow[1][r] = fmaxf((half ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1]) + bias_v, 0.f);
+        }
     }
     __syncthreads();                                    // exchange area is dead: reuse as store staging
     float* stg = reinterpret_cast<float*>(lds) + wave * (64 * WS32);
