@@ -197,7 +197,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batch={B} per GPU, {S}x{S}x3 fp32 forward, HIP conv kernels"
+            "config": {"workload": f"BASELINE configs[{1 if S == 128 else 3}]: batch={B} per GPU, {S}x{S}x3 fp32 forward, HIP conv kernels"
                                    + (f" (global batch {B * world} sharded over {world} GPUs, configs[2] shape)" if world > 1 else ""),
                        "global_batch": B * world, "image": [S, S, 3], "weights": f"synthetic seeded ({args.weights})", "conv3x3_algo": args.algo,
                        "parallelism": f"dp{world}", "inputs": "resident in HBM"},

@@ -59,8 +59,8 @@ __device__ __forceinline__ int lds_slot(int p, int c) { return p * PSLOTS + c; }
 // 8 XCDs, so id%8 labels the XCD group; each group walks a contiguous range of tiles (whole
 // images, neighbouring halos) and the NB column blocks of one tile run back to back on it, so
 // the halo tile and the layer's weights stay in that XCD's L2.  Placement only affects speed.
-__device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd, int NB, int& mt, int& nb) {
-    const int id = blockIdx.x;
+__device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd, int NB, int& mt, int& nb, int id = -1) {
+    if (id < 0) id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
     nb = slot % NB;
     mt = xcd * tiles_per_xcd + slot / NB;

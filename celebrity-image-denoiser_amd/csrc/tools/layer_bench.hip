@@ -48,7 +48,7 @@ static Variant makew(const char* name, int N, int H, int W, float* in, float* u,
     constexpr int BTR = 2 * (32 / TC);
     a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);
     a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
-    const int grid = 8 * a.tiles_per_xcd * (COUT / WN);
+    const int grid = 8 * a.tiles_per_xcd * (COUT / WN) / ((ABLATE & 128) ? 2 : 1);
     const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;   // algorithmic (direct) FLOPs
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
 }
@@ -72,6 +72,9 @@ int main(int argc, char** argv) {
     float* uB = dalloc((size_t)256 * 256 * 16, 0.05f);
     v.push_back(make<128, 64, 0, 0, 2>("A direct 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
     v.push_back(makew<128, 64, false, 32, 0>("A wino base", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 128>("A wino 2-items/WG", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 128 + 15>("A wino mfma-only 2-items/WG", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew<128, 64, false, 32, 64>("A wino no-stagger", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew<128, 64, false, 32, 1>("A wino no-halo-prefetch", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew<128, 64, false, 32, 2>("A wino no-B-loads", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew<128, 64, false, 32, 4>("A wino no-A-build", N, 128, 128, inA, uA, bA, outA, poolA));
@@ -81,6 +84,7 @@ int main(int argc, char** argv) {
     v.push_back(makew<128, 64, false, 32, 15>("A wino mfma-only", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(make<256, 256, 0, 0, 2>("B direct 256->256@32", N, 32, 32, inB, wB, bB, outB, nullptr));
     v.push_back(makew<256, 256, false, 16, 0>("B wino base", N, 32, 32, inB, uB, bB, outB, nullptr));
+    v.push_back(makew<256, 256, false, 16, 64>("B wino no-stagger", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew<256, 256, false, 16, 2>("B wino no-B-loads", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew<256, 256, false, 16, 15>("B wino mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
     std::vector<std::vector<float>> ms(v.size());

@@ -48,8 +48,25 @@ struct WinoArgs {
 // ABLATE (timing experiments only, csrc/tools/layer_bench.hip; results are wrong when non-zero):
 //   bit 0: no halo prefetch after chunk 0   bit 1: B fragments loaded once   bit 2: A operand built once
 //   bit 3: no epilogue                      bit 4: A operand read from LDS but not transformed
+//   bit 5: no prologue DMA                  bit 6: no start-up stagger of odd wave slots
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
+__device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int item);
+
 template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
+    constexpr int LDS_SLOTS_K = 4096;
+    __shared__ f32x4 lds[LDS_SLOTS_K];
+    if (ABLATE & 128) {   // experiment: two work items per workgroup, back to back (grid halved by the launcher)
+        wino_item<CIN, COUT, POOL, TC, ABLATE>(a, lds, blockIdx.x);
+        __syncthreads();
+        wino_item<CIN, COUT, POOL, TC, ABLATE>(a, lds, blockIdx.x + gridDim.x);
+    } else {
+        wino_item<CIN, COUT, POOL, TC, ABLATE>(a, lds, blockIdx.x);
+    }
+}
+
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
+__device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int item) {
     constexpr int TRP = 32 / TC;                 // tile rows per pair
     constexpr int BTR = 2 * TRP;                 // tile rows per workgroup
     constexpr int LW = 2 * TC + 2, LH = 2 * BTR + 2, LPIX = LW * LH;
@@ -62,12 +79,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     static_assert(RW <= 8 && CIN * 4 <= 4096, "DMA rounds per wave / zero page size");
 
     constexpr int EXCH = 4 * 16 * 64;            // epilogue exchange area: 4 waves x 16 registers x 64 lanes (f32x4)
-    constexpr int LDS_SLOTS = (2 * BUF > EXCH) ? 2 * BUF : EXCH;
-    __shared__ f32x4 lds[LDS_SLOTS];
-    static_assert(4 * 64 * WS32 * sizeof(float) <= sizeof(lds), "store staging");
+    static_assert(2 * BUF <= 4096 && EXCH <= 4096 && 4 * 64 * WS32 * sizeof(float) <= 4096 * 16, "LDS budget (64 KiB)");
 
     int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb, item)) return;
     const int tx = mt % a.tiles_x;
     const int ty = (mt / a.tiles_x) % a.tiles_y;
     const int n = mt / (a.tiles_x * a.tiles_y);
@@ -81,6 +96,19 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino_conv(const WinoArgs a) {
     const int tr = i / TC, tc = i - tr * TC;
 
     const float bias_v = a.bias[nb * WN + i];
+
+    // De-phase the two workgroups that share a CU.  All workgroups of this launch take the same time, so the two
+    // resident on a CU would start, reach their seams and finish together for the whole launch, and every
+    // prologue/epilogue (LDS-DMA latency, output transform, stores) would find the SIMD's other wave in the
+    // same idle phase.  The waves that landed in an odd wave slot of their SIMD (HW_ID.WAVE_ID) wait half a
+    // workgroup's duration once, in the first generation only; later generations inherit the offset.
+    if (!(ABLATE & 64) && item < 2 * 256) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) {
+            for (int sl = 0; sl < NCHUNK / 2; ++sl) __builtin_amdgcn_s_sleep(127);   // ~NCHUNK*4096 cycles
+        }
+    }
 
     // rows of the 4x4 input patch that feed row a of B^T d:  t = x + sgn*y
     //   a=0: d0 - d2   a=1: d1 + d2   a=2: d2 - d1   a=3: d1 - d3
