@@ -17,6 +17,8 @@ _LAZY = {
     "load": ("api", "load"),
     "denoise": ("api", "denoise"),
     "denoise_u8": ("api", "denoise_u8"),
+    "serve_u8": ("api", "serve_u8"),
+    "get_padding": ("api", "get_padding"),
     "load_state_safely": ("api", "load_state_safely"),
     "psnr": ("metrics", "psnr"),
 }

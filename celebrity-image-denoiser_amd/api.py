@@ -100,6 +100,34 @@ def denoise_u8(model: DenoiseGenerator, images_u8: torch.Tensor, max_batch: Opti
     return y.to(src_dev)
 
 
+def get_padding(width: int, height: int, divisor: int = 4, scale: int = 1):
+    """(left, top, right, bottom) that brings width/height up to a multiple of divisor*scale, split as evenly as
+    integer halves allow with the extra pixel on the right/bottom — the reference's rule (app.py:276-281)."""
+    d = divisor * scale
+    pad_w = (d - width % d) % d
+    pad_h = (d - height % d) % d
+    return (pad_w // 2, pad_h // 2, pad_w - pad_w // 2, pad_h - pad_h // 2)
+
+
+def serve_u8(model: DenoiseGenerator, images_u8: torch.Tensor, pad_divisor: int = 4) -> torch.Tensor:
+    """The reference server's denoise path for images of ANY size (app.py:378-385, 400-406, 433-435, 471-480):
+    pad the uint8 image with black to a multiple of `pad_divisor` (transforms.Pad(fill=0), i.e. -1 after
+    normalisation), normalise, run the network, map back to uint8, crop the padding off again.
+    images_u8: uint8 [N,H,W,3] (host or GPU) -> uint8 [N,H,W,3], same place.  The pad and the crop are device
+    memory copies; everything numeric runs in the fused-u8 kernels (forward_u8)."""
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
+        raise RuntimeError("serve_u8 expects a uint8 tensor of shape [N,H,W,3]")
+    dev = next(model.parameters()).device
+    src_dev = images_u8.device
+    n, h, w, _ = images_u8.shape
+    left, top, right, bottom = get_padding(w, h, pad_divisor)
+    x = images_u8.to(dev, non_blocking=True)
+    if left or top or right or bottom:
+        x = torch.nn.functional.pad(x, (0, 0, left, right, top, bottom), mode="constant", value=0)
+    y = model.forward_u8(x)
+    return y[:, top:top + h, left:left + w, :].contiguous().to(src_dev)
+
+
 def to_unit_range(y: torch.Tensor) -> torch.Tensor:
     """The reference's view transform for tanh-range outputs: y*0.5+0.5 clamped to [0,1] (app.py:435)."""
     return (y * 0.5 + 0.5).clamp(0, 1)

@@ -104,6 +104,20 @@ def main():
             yt = model(xt)
         y_u8 = (yt * 0.5 + 0.5).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).contiguous().numpy()
         np.savez_compressed(os.path.join(HERE, f"u8_{wset}_32x40.npz"), noisy_u8=noisy_u8, out_u8=y_u8, out_f32=yt.numpy())
+        # f4 row: an image whose size is not a multiple of 4 goes through the server's pad -> net -> crop
+        # (app.py:276-281,384-385 get_padding/transforms.Pad(fill=0); :474-480 crop), pre/post as above.
+        _, _, odd_u8 = synth.make_batch(1, 30, 45, 70)
+        w_, h_ = 45, 30
+        pw, ph = (4 - w_ % 4) % 4, (4 - h_ % 4) % 4
+        left, top, right, bottom = pw // 2, ph // 2, pw - pw // 2, ph - ph // 2
+        padded = np.zeros((1, h_ + top + bottom, w_ + left + right, 3), np.uint8)
+        padded[:, top:top + h_, left:left + w_] = odd_u8
+        xt = (torch.from_numpy(padded).permute(0, 3, 1, 2).to(torch.float32).div(255) - 0.5) / 0.5
+        with torch.no_grad():
+            yt = model(xt)
+        y_u8 = (yt * 0.5 + 0.5).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).numpy()
+        np.savez_compressed(os.path.join(HERE, f"pad_{wset}_30x45.npz"), image_u8=odd_u8,
+                            out_u8=np.ascontiguousarray(y_u8[:, top:top + h_, left:left + w_]), padding=np.array([left, top, right, bottom]))
         for tag, (n, h, w, first) in {"n4_128": (4, 128, 128, 200), "n1_256": (1, 256, 256, 300)}.items():
             x, clean, _ = synth.make_batch(n, h, w, first)
             r = run(model, x)

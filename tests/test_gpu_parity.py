@@ -240,3 +240,17 @@ def test_u8_in_u8_out_golden(models, golden_dir, wset):
     # fused normalisation == explicit normalisation followed by the fp32 forward, bit for bit
     x = synth.normalize_u8(g["noisy_u8"])
     assert np.array_equal(_run(m, x), y_f32)
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_serve_any_size_pad_and_crop(models, golden_dir, wset):
+    """a 30x45 image through pad-to-multiple-of-4 -> network -> crop, like the reference server
+    (app.py:276-281,384-385,474-480), against the fixture made with the reference module."""
+    import celebrity_image_denoiser_amd as cid
+
+    g = np.load(os.path.join(golden_dir, f"pad_{wset}_30x45.npz"))
+    assert tuple(g["padding"]) == cid.get_padding(45, 30, 4) == (1, 1, 2, 1)
+    y = cid.serve_u8(models[wset], torch.from_numpy(g["image_u8"])).numpy()
+    assert y.shape == g["image_u8"].shape == g["out_u8"].shape
+    d = np.abs(y.astype(np.int16) - g["out_u8"].astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3

@@ -109,3 +109,11 @@ def test_shard_range_partitions_the_batch():
     assert cdist.shard_range(2048, 3, 8) == (768, 1024)              # config 3: 256 images per GPU
     with pytest.raises(ValueError):
         cdist.shard_range(8, 2, 2)
+
+
+def test_get_padding_rule():
+    """app.py:276-281: pad to a multiple of divisor*scale, extra pixel on the right/bottom."""
+    assert cid.get_padding(128, 128) == (0, 0, 0, 0)
+    assert cid.get_padding(45, 30) == (1, 1, 2, 1)
+    assert cid.get_padding(127, 130) == (0, 1, 1, 1)
+    assert cid.get_padding(5, 5, divisor=4, scale=4) == (5, 5, 6, 6)
