@@ -56,8 +56,13 @@ def load(source: Union[str, Mapping, None] = None, device: Optional[Union[str, t
         raise RuntimeError("celebrity_image_denoiser_amd.load: an AMD GPU is required (no CPU fallback)")
     model = DenoiseGenerator()
     if isinstance(source, str):
-        ckpt = torch.load(source, map_location="cpu", weights_only=False)
-        model.load_state_dict(extract_state_dict(ckpt), strict=strict)
+        try:   # torch-free reader first (closed allow-list, nothing in the file can execute): ckpt.py
+            from .ckpt import read_state_dict
+
+            state = {k: torch.from_numpy(v) for k, v in read_state_dict(source).items()}
+        except Exception:   # legacy (non-zip) formats
+            state = extract_state_dict(torch.load(source, map_location="cpu", weights_only=False))
+        model.load_state_dict(state, strict=strict)
     elif source is not None:
         sd = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in extract_state_dict(source).items()}
         model.load_state_dict(sd, strict=strict)

@@ -117,3 +117,33 @@ def test_get_padding_rule():
     assert cid.get_padding(45, 30) == (1, 1, 2, 1)
     assert cid.get_padding(127, 130) == (0, 1, 1, 1)
     assert cid.get_padding(5, 5, divisor=4, scale=4) == (5, 5, 6, 6)
+
+
+def test_torch_free_checkpoint_reader(tmp_path):
+    """read the trainer's checkpoint layout (training.py:359-376) without torch.load."""
+    from celebrity_image_denoiser_amd import ckpt
+
+    sd = {("module." + k): torch.from_numpy(v) for k, v in synth.make_state_dict("hot").items()}
+    # a non-contiguous tensor and a 0-dim tensor exercise stride / scalar handling
+    extra = torch.arange(24, dtype=torch.float32).reshape(4, 6).t()
+    path = os.path.join(tmp_path, "denoise_epoch_499.pth")
+    torch.save({"generator": sd, "discriminator": {"w": extra, "s": torch.tensor(3.5)}, "epoch": 499,
+                "best_psnr": 31.25, "metric_history": {"psnr": [1.0, 2.0]},
+                "g_optimizer": {"state": {}, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999), "params": [0, 1]}]}}, path)
+    whole = ckpt.read_checkpoint(path)
+    assert whole["epoch"] == 499 and whole["best_psnr"] == 31.25 and whole["g_optimizer"]["param_groups"][0]["betas"] == (0.9, 0.999)
+    assert np.array_equal(whole["discriminator"]["w"], extra.numpy()) and float(whole["discriminator"]["s"]) == 3.5
+    got = ckpt.read_state_dict(path)
+    ref = synth.make_state_dict("hot")
+    assert list(got.keys()) == list(ref.keys())
+    assert all(np.array_equal(got[k], ref[k]) and got[k].dtype == np.float32 for k in ref)
+    # and it feeds the module like torch.load would
+    m = cid.DenoiseGenerator()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in got.items()}, strict=True)
+    # a pickle that names anything outside the allow-list is refused, not executed
+    import pickle, zipfile
+    evil = os.path.join(tmp_path, "evil.pth")
+    with zipfile.ZipFile(evil, "w") as zf:
+        zf.writestr("archive/data.pkl", pickle.dumps(os.getcwd))
+    with pytest.raises(pickle.UnpicklingError):
+        ckpt.read_checkpoint(evil)
