@@ -87,6 +87,13 @@ int main(int argc, char** argv) {
     v.push_back(makew<256, 256, false, 16, 64>("B wino no-stagger", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew<256, 256, false, 16, 2>("B wino no-B-loads", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew<256, 256, false, 16, 15>("B wino mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
+    {   // up1 shape: ConvT 128 -> 64 on 64x64 inputs (output 128x128x64); reuse inA (>= N*64*64*128) and outA
+        v.push_back(make<128, 64, 2, 0, 2>("T convT 128->64@64 base", N, 64, 64, inA, wA, bA, outA, nullptr));
+        v.push_back(make<128, 64, 2, 1, 2>("T no-halo-prefetch", N, 64, 64, inA, wA, bA, outA, nullptr));
+        v.push_back(make<128, 64, 2, 2, 2>("T no-B-loads", N, 64, 64, inA, wA, bA, outA, nullptr));
+        v.push_back(make<128, 64, 2, 8, 2>("T no-stores", N, 64, 64, inA, wA, bA, outA, nullptr));
+        v.push_back(make<128, 64, 2, 15, 2>("T mfma-only", N, 64, 64, inA, wA, bA, outA, nullptr));
+    }
     std::vector<std::vector<float>> ms(v.size());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& x : v) x.run(s);   // warm-up

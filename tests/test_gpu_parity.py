@@ -254,3 +254,32 @@ def test_serve_any_size_pad_and_crop(models, golden_dir, wset):
     assert y.shape == g["image_u8"].shape == g["out_u8"].shape
     d = np.abs(y.astype(np.int16) - g["out_u8"].astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+
+
+def test_hip_graph_capture_and_replay(weight_sets):
+    """cid_forward only enqueues kernels (no allocation, no synchronisation), so a forward can be captured into
+    a HIP graph on the caller's stream and replayed: the replay must reproduce the eager result bit for bit and
+    follow new input contents."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    x1 = torch.from_numpy(synth.make_batch(4, 64, 64, first_index=1500)[0]).to("cuda:0")
+    x2 = torch.from_numpy(synth.make_batch(4, 64, 64, first_index=1600)[0]).to("cuda:0")
+    static_x = x1.clone()
+    m(static_x)                                     # packs weights and sizes the arena outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            static_y = m(static_x)
+    torch.cuda.current_stream().wait_stream(s)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, m(x1))
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, m(x2)) and not torch.equal(m(x1), m(x2))
