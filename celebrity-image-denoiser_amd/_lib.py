@@ -12,6 +12,7 @@ CID_NUM_PARAMS = 24
 CID_NUM_LAUNCHES = 12
 CID_ALGO_DIRECT, CID_ALGO_WINOGRAD = 0, 1
 CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
+CID_DTYPE_F32, CID_DTYPE_F16 = 0, 1
 
 # every symbol include/cid.h declares: (restype, argtypes)
 _c = ctypes
@@ -43,6 +44,8 @@ SYMBOLS = {
     "cid_launch_kernel": (_c.c_char_p, [_c.c_void_p, _c.c_int]),
     "cid_set_conv_algo": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_conv_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "cid_set_compute_dtype": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "cid_get_compute_dtype": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_launch_work": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/cid.h"
 #include "conv_kernels.h"
 #include "wino_kernels.h"
+#include "conv_kernels_f16.h"
 
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,11 @@ const char* kKernelNames[NL] = {
     "k_gemm_conv<128, 128, 0,", "k_gemm_conv<128, 64, 2,", "k_gemm_conv<128, 64, 0,", "k_conv_tail",
 };
 
+const char* kHalfKernelNames[NL] = {
+    "k_conv_head", "k_gemm_conv_h<64, 64, 1>", "k_gemm_conv_h<64, 128, 0>", "k_gemm_conv_h<128, 128, 1>",
+    "k_gemm_conv_h<128, 256, 0>", "k_gemm_conv_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_gemm_conv_h<256, 128, 0>",
+    "k_gemm_conv_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_gemm_conv_h<128, 64, 0>", "k_conv_tail",
+};
 const char* kWinoKernelNames[NL] = {
     nullptr, "k_wino_conv<64, 64, true,", "k_wino_conv<64, 128, false,", "k_wino_conv<128, 128, true,",
     "k_wino_conv<128, 256, false,", "k_wino_conv<256, 256, false,", nullptr, "k_wino_conv<256, 128, false,",
@@ -52,7 +58,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -62,6 +68,10 @@ struct BlobLayout {
         for (int l = 0; l < NL; ++l) {
             u_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 16, 64);
+        }
+        for (int l = 0; l < NL; ++l) {   // fp16-storage path: half weights of the GEMM layers (2 per float slot)
+            h_off[l] = o;
+            if (kLayers[l].kind == CONV || kLayers[l].kind == CONVT) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
         }
         for (int l = 0; l < NL; ++l) {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
@@ -128,6 +138,18 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
         }
 }
 
+// fp16-storage path: [nb][chunk][tap][k-step][ns][lane = 32*h + j][8] halfs with ci = 32*chunk + 16*kstep + 8*h + e,
+// n' = 64*nb + 32*ns + j — lane (h, j) of v_mfma_f32_32x32x16_f16 holds B[k = 8h..8h+7][col = j].
+size_t packed_index_h(const LayerDef& L, int co, int ci, int kh, int kw) {
+    const int taps = L.kind == CONV ? 9 : 1;
+    const int tap = L.kind == CONV ? kh * 3 + kw : 0;
+    const int np = L.kind == CONV ? co : (kh * 2 + kw) * L.cout + co;
+    const int nb = np >> 6, ns = (np >> 5) & 1, j = np & 31;
+    const int ck = ci >> 5, ks = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
+    const int nchunk = L.cin / 32;
+    return (((((size_t)(nb * nchunk + ck) * taps + tap) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
+}
+
 struct Dims {
     int N, H, W, H1, W1, H2, W2, Hu2, Wu2, Hu1, Wu1;
 };
@@ -159,6 +181,7 @@ struct cid_handle_s {
     bool have[NL][2];
     const float* dev_blob = nullptr;
     std::string err;
+    int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
     int algo = CID_ALGO_WINOGRAD;      // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
@@ -243,14 +266,51 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
 
-hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8) {
-    if (u8) hipLaunchKernelGGL(k_conv_head<true>, dim3(grid), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_conv_head<false>, dim3(grid), dim3(THREADS), 0, s, a);
+template <int CIN, int COUT, int MODE>
+hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void* in, int Hin, int Win, int in_ps,
+                         void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N);
+
+// One GEMM-shaped layer under the handle's storage type and algorithm.  The arena regions are sized for fp32; the
+// fp16-storage path keeps its half tensors in the front half of the same regions.
+template <int CIN, int COUT, int MODE>
+hipError_t launch_layer(cid_handle_t h, hipStream_t s, const float* blob, int layer, float* in, int Hin, int Win, int in_ps,
+                        float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
+    if (h->dtype == CID_DTYPE_F16)
+        return launch_gemm_h<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+    if constexpr (MODE == 2)
+        return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+    else
+        return launch_conv3x3<CIN, COUT, MODE>(h->algo, s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+}
+
+hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8, bool f16) {
+    if (u8 && f16) hipLaunchKernelGGL((k_conv_head<true, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (u8) hipLaunchKernelGGL((k_conv_head<true, false>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (f16) hipLaunchKernelGGL((k_conv_head<false, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_head<false, false>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8) {
-    if (u8) hipLaunchKernelGGL(k_conv_tail<true>, dim3(grid), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_conv_tail<false>, dim3(grid), dim3(THREADS), 0, s, a);
+hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8, bool f16) {
+    if (u8 && f16) hipLaunchKernelGGL((k_conv_tail<true, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (u8) hipLaunchKernelGGL((k_conv_tail<true, false>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (f16) hipLaunchKernelGGL((k_conv_tail<false, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_tail<false, false>), dim3(grid), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int CIN, int COUT, int MODE>
+hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void* in, int Hin, int Win, int in_ps,
+                         void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N) {
+    GemmConvArgsH a;
+    a.in = static_cast<const _Float16*>(in); a.w = reinterpret_cast<const _Float16*>(blob + kBlob.h_off[layer]);
+    a.bias = blob + kBlob.b_off[layer];
+    a.out = static_cast<_Float16*>(out); a.pool = static_cast<_Float16*>(pool);
+    a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps;
+    a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
+    const TileGrid g = tiles_for(N, Hc, Wc);
+    a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+    constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
+    hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -293,33 +353,33 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
-        STEP(launch_head(s, a, 8 * g.per_xcd, in_fmt == CID_FMT_U8_NHWC));
+        STEP(launch_head(s, a, 8 * g.per_xcd, in_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
-    STEP((launch_conv3x3<64, 64, 1>(h->algo, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
+    STEP((launch_layer<64, 64, 1>(h, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
     // down2[0] + ReLU                                                                    app.py:51-52
-    STEP((launch_conv3x3<64, 128, 0>(h->algo, s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
+    STEP((launch_layer<64, 128, 0>(h, s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
     // down2[2] + ReLU -> e2 into cat2[:, 128:256] (cropped), pool2 -> p2                 app.py:53-56,90-93
-    STEP((launch_conv3x3<128, 128, 1>(h->algo, s, blob, 3, B[T1], d.H1, d.W1, 128, B[CAT2], 256, 128, d.Hu2, d.Wu2, d.Hu2, d.Wu2, B[P2], N)));
+    STEP((launch_layer<128, 128, 1>(h, s, blob, 3, B[T1], d.H1, d.W1, 128, B[CAT2], 256, 128, d.Hu2, d.Wu2, d.Hu2, d.Wu2, B[P2], N)));
     // bottleneck                                                                         app.py:59-62
-    STEP((launch_conv3x3<128, 256, 0>(h->algo, s, blob, 4, B[P2], d.H2, d.W2, 128, B[T2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
-    STEP((launch_conv3x3<256, 256, 0>(h->algo, s, blob, 5, B[T2], d.H2, d.W2, 256, B[BT], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_layer<128, 256, 0>(h, s, blob, 4, B[P2], d.H2, d.W2, 128, B[T2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_layer<256, 256, 0>(h, s, blob, 5, B[T2], d.H2, d.W2, 256, B[BT], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
     // up2: ConvT 256->128 -> cat2[:, 0:128]                                              app.py:65,89
-    STEP((launch_gemm<256, 128, 2>(s, blob, 6, B[BT], d.H2, d.W2, 256, B[CAT2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
+    STEP((launch_layer<256, 128, 2>(h, s, blob, 6, B[BT], d.H2, d.W2, 256, B[CAT2], 256, 0, d.H2, d.W2, d.H2, d.W2, nullptr, N)));
     // upconv2                                                                            app.py:67-70
-    STEP((launch_conv3x3<256, 128, 0>(h->algo, s, blob, 7, B[CAT2], d.Hu2, d.Wu2, 256, B[T3], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
-    STEP((launch_conv3x3<128, 128, 0>(h->algo, s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_layer<256, 128, 0>(h, s, blob, 7, B[CAT2], d.Hu2, d.Wu2, 256, B[T3], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_layer<128, 128, 0>(h, s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // up1: ConvT 128->64 -> cat1[:, 0:64]                                                app.py:73,96
-    STEP((launch_gemm<128, 64, 2>(s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    STEP((launch_layer<128, 64, 2>(h, s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // upconv1[0] + ReLU                                                                  app.py:75-76
-    STEP((launch_conv3x3<128, 64, 0>(h->algo, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
+    STEP((launch_layer<128, 64, 0>(h, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
     {   // upconv1[2] + tanh, NHWC t4 -> NCHW out                                         app.py:77,103
         TailArgs a;
         a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
-        STEP(launch_tail(s, a, 8 * g.per_xcd, out_fmt == CID_FMT_U8_NHWC));
+        STEP(launch_tail(s, a, 8 * g.per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
 #undef STEP
     if (ev && hipEventRecord(ev[NL], s) != hipSuccess) return fail(h, CID_ERR_HIP, "hipEventRecord failed");
@@ -379,6 +439,10 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
         std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
         if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l]);
+        if (L.kind == CONV || L.kind == CONVT) {
+            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
+        }
     }
     h->have[l][is_bias] = true;
     return CID_OK;
@@ -532,6 +596,7 @@ int cid_forward_timed(cid_handle_t h, const float* in, float* out, int N, int H,
 const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name : nullptr; }
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
+    if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
     return (h && h->algo == 1 && kWinoKernelNames[i]) ? kWinoKernelNames[i] : kKernelNames[i];
 }
 
@@ -539,6 +604,17 @@ int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
     if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
+    return CID_OK;
+}
+int cid_set_compute_dtype(cid_handle_t h, int dtype) {
+    if (!h) return CID_ERR_INVALID;
+    if (dtype != CID_DTYPE_F32 && dtype != CID_DTYPE_F16) return fail(h, CID_ERR_INVALID, "cid_set_compute_dtype: unknown dtype");
+    h->dtype = dtype;
+    return CID_OK;
+}
+int cid_get_compute_dtype(cid_handle_t h, int* dtype) {
+    if (!h || !dtype) return CID_ERR_INVALID;
+    *dtype = h->dtype;
     return CID_OK;
 }
 int cid_get_conv_algo(cid_handle_t h, int* algo) {

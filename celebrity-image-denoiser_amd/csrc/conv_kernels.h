@@ -27,6 +27,8 @@ namespace cid {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_H = 8;    // output rows per workgroup
 constexpr int TILE_W = 32;   // output columns per workgroup (= one MFMA M dimension)
@@ -103,6 +105,32 @@ __device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixF
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 15) * 4);
         float* g = ptr(px);
         if (g) *reinterpret_cast<f32x4*>(g + (lane & 15) * 4) = v;
+    }
+    wave_lds_fence();
+}
+
+// Same slab, rounded to IEEE half on the way out: 8 channels (16 bytes) per lane, 8 lanes per pixel, 8 pixels
+// per instruction.  Used by the fp16-storage path (conv_kernels_f16.h) and by the head when it feeds that path.
+template <int NPIX, typename ValFn, typename PixFn, typename PtrFn>
+__device__ __forceinline__ void wide_store_h(float* stg, int lane, ValFn val, PixFn pix, PtrFn ptr) {
+    const int i = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NPIX / 2; ++k) {
+        const int px = pix(k);
+        stg[px * WS_STRIDE + i] = val(0, k);
+        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < NPIX / 8; ++it) {
+        const int px = it * 8 + (lane >> 3);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
+        _Float16* g = ptr(px);
+        if (g) *reinterpret_cast<f16x8*>(g + (lane & 7) * 8) = v;
     }
     wave_lds_fence();
 }
@@ -327,14 +355,14 @@ struct HeadArgs {
     const void* in;     // fp32 NCHW [N,3,H,W], or (IN_U8) uint8 NHWC [N,H,W,3]
     const float* w;     // packed [2 ns][14 steps][64 lanes]
     const float* bias;  // [64]
-    float* out;         // NHWC [N,H,W,64]
+    void* out;          // NHWC [N,H,W,64]: fp32, or (OUT_F16) half for the fp16-storage path
     int N, H, W;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
 };
 
 // IN_U8: the caller's image is uint8 HWC (what PIL hands the reference); ToTensor (/255) and Normalize(0.5,0.5)
 // (app.py:401-405) are applied on the fly, in fp32, with true divisions like torchvision: (u8/255 - 0.5)/0.5.
-template <bool IN_U8>
+template <bool IN_U8, bool OUT_F16 = false>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;   // 34 used columns, padded to 36
     __shared__ __attribute__((aligned(16))) float lds[4 * WS_FLOATS];   // input planes (3*PLANE floats), then store staging
@@ -400,12 +428,18 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int y = y0 + 2 * wave + m;
-        float* orow = a.out + ((size_t)(n * a.H + y) * a.W) * 64;
         const bool rowok = y < a.H;
-        wide_store<32>(stg, lane,
-                       [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); },
-                       [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; },
-                       [&](int px) -> float* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+        auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
+        auto pix = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
+        if (OUT_F16) {
+            _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
+            wide_store_h<32>(stg, lane, val, pix,
+                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+        } else {
+            float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
+            wide_store<32>(stg, lane, val, pix,
+                           [&](int px) -> float* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+        }
     }
 }
 
@@ -418,7 +452,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 // tanh and is written straight into the caller's NCHW tensor (the NHWC -> NCHW change of layout is
 // folded in).  HBM-bound on the 64-channel NHWC input it reads once.
 struct TailArgs {
-    const float* in;    // NHWC [N,H,W,64]
+    const void* in;     // NHWC [N,H,W,64]: fp32, or (IN_F16) half from the fp16-storage path
     const float* w;     // packed [2 chunk][4 group][64 lanes][4]  (cid_api.hip packed_index, TAIL)
     const float* bias;  // [3]
     void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
@@ -428,7 +462,7 @@ struct TailArgs {
 
 // OUT_U8: the reference's view transform and PIL conversion folded in: y*0.5+0.5, clamp to [0,1] (app.py:435),
 // then ToPILImage's mul(255).byte() — truncation, not rounding (app.py:471-472; denoisegan_eval.py:97-98).
-template <bool OUT_U8>
+template <bool OUT_U8, bool IN_F16 = false>
 __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;   // 340 halo pixels
     constexpr int MT = (LPIX + 31) / 32, LP = MT * 32;                // 11 M tiles, 352 rows
@@ -459,7 +493,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const float* inb = a.in + (size_t)n * a.H * a.W * 64;
+    const size_t img_off = (size_t)n * a.H * a.W * 64;
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
         f32x4 stage[NLOAD];
@@ -470,7 +504,15 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
             const int hy = p / LW, hx = p - hy * LW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool ok = (s < NSLOT) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            f32x4 v = *reinterpret_cast<const f32x4*>(inb + (ok ? ((gy * a.W + gx) * 64 + c * 4) : 0) + ck * KCHUNK);
+            const int off = (ok ? ((gy * a.W + gx) * 64 + c * 4) : 0) + ck * KCHUNK;
+            f32x4 v;
+            if (IN_F16) {
+                const f16x4 hv = *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(a.in) + img_off + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)hv[e];
+            } else {
+                v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.in) + img_off + off);
+            }
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             stage[it] = v;
         }

@@ -1,0 +1,195 @@
+// conv_kernels_f16.h — fp16-storage / fp32-accumulate variant of the GEMM-shaped layers (BASELINE configs[4]).
+//
+// Same function, tiling and fused epilogues as k_gemm_conv (conv_kernels.h; reference backend/app.py:43-77),
+// with activations and weights held as IEEE half in HBM/LDS and the contraction on
+// v_mfma_f32_32x32x16_f16 (16 input channels per instruction, fp32 accumulators).  Bias, ReLU, max-pool
+// and the transposed-convolution scatter are applied to the fp32 accumulators; results are rounded to half
+// once, at the store.  This is a separate numerical contract from the fp32 path (stated tolerance in
+// tests/test_gpu_parity.py), selected with cid_set_compute_dtype.
+//
+//   * workgroup = 8x32 output pixels x 64 channels, wave = 64 pixels x 64 channels (2x2 MFMA tiles);
+//   * K = (32-channel chunk) x (tap) x (16-channel k-step); per k-step and wave: two ds_read_b128 (A: lane
+//     (i,h) takes channels 8h..8h+7 of pixel i) and two 1 KiB B quads (pre-packed per lane), four MFMAs;
+//   * LDS halo tile: pixel = 64 B of data + 16 B pad (5 slots): consecutive pixels are conflict-free for
+//     ds_read_b128; fetched global -> registers -> LDS one piece per step under the MFMAs, like k_gemm_conv;
+//   * store tail: fp32 staging in LDS (wide_store layout), converted to half on the way out, 16 B per lane.
+#pragma once
+#include "conv_kernels.h"
+
+namespace cid {
+
+constexpr int HPS = 5;   // LDS slots (16 B) per pixel: 4 data (32 halfs) + 1 pad
+
+struct GemmConvArgsH {
+    const _Float16* in;   // NHWC half [N, Hin, Win, in_ps]
+    const _Float16* w;    // packed: [nb][chunk][tap][kstep][ns][lane][8]
+    const float* bias;    // [COUT] fp32
+    _Float16* out;
+    _Float16* pool;
+    int N, Hin, Win, in_ps;
+    int Hc, Wc, Hs, Ws;
+    int out_ps, out_coff;
+    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+};
+
+template <int CIN, int COUT, int MODE>
+__global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH a) {
+    constexpr int TAPS = (MODE == 2) ? 1 : 9;
+    constexpr int HALO = (MODE == 2) ? 0 : 1;
+    constexpr int LW = TILE_W + 2 * HALO, LH = TILE_H + 2 * HALO, LPIX = LW * LH;
+    constexpr int NSLOT = LPIX * 4;                  // 16-byte data slots (8 halfs) per chunk tile
+    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;
+    constexpr int NCHUNK = CIN / KCHUNK;             // 32-channel chunks
+    constexpr int NOUT = (MODE == 2) ? 4 * COUT : COUT;
+    constexpr int NB = NOUT / NTILE;
+    constexpr int SPC = TAPS * 2;                    // k-steps (16 channels each) per chunk
+    static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0, "layer dims");
+    constexpr int LDS_SLOTS = (LPIX * HPS * 16 > 4 * WS_FLOATS * 4) ? LPIX * HPS : (4 * WS_FLOATS * 4 + 15) / 16;
+    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile (half), later the fp32 store staging
+
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    const int tx = mt % a.tiles_x;
+    const int ty = (mt / a.tiles_x) % a.tiles_y;
+    const int n = mt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+
+    constexpr int CB = COUT / NTILE;
+    const int tap2 = (MODE == 2) ? nb / CB : 0;
+    const int cobase = ((MODE == 2) ? (nb - tap2 * CB) : nb) * NTILE;
+    float bias_v[2];
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
+
+    // ---- this thread's pieces of the halo tile: piece `it` is data slot s = it*256 + tid (pixel s/4, slot s%4) ----
+    const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
+    int goff[NLOAD];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+        const int s = it * THREADS + tid;
+        const int p = s >> 2, c = s & 3;
+        const int hy = p / LW, hx = p - hy * LW;
+        const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
+        const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        goff[it] = ok ? ((gy * a.Win + gx) * a.in_ps + c * 8) : 0;
+        okmask |= (ok ? 1u : 0u) << it;
+    }
+    const int wslot = (tid >> 2) * HPS + (tid & 3);   // piece `it` lands at wslot + it*64*HPS
+    auto halo_load = [&](int it, int ck) -> f32x4 { return *reinterpret_cast<const f32x4*>(inb + goff[it] + ck * KCHUNK); };
+    auto halo_store = [&](int it, f32x4 v) {
+        if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding (half 0 == all-zero bits)
+        if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[wslot + it * 64 * HPS] = v;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
+
+    const int pbase0 = ((2 * wave) * LW + i) * HPS + h;   // slot of (row 2*wave, column i), tap (0,0), k-step 0
+    const f16x8* wp = reinterpret_cast<const f16x8*>(a.w) + ((size_t)nb * NCHUNK * SPC) * 128 + lane;
+
+    f32x4 pre[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
+    f16x8 bcur[2], bnxt[2];
+    bcur[0] = wp[0];
+    bcur[1] = wp[64];
+    wp += 128;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+    __syncthreads();
+
+    const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
+    auto chunk = [&](auto pref_tag, int ck) {
+        constexpr bool PREF = decltype(pref_tag)::value;
+        f16x8 acur[2], anxt[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * HPS];
+#pragma unroll
+        for (int st = 0; st < SPC; ++st) {
+            if (st + 1 < SPC) {
+                const int t2 = (st + 1) >> 1, ks2 = (st + 1) & 1;
+                const int off = ((TAPS == 9) ? ((t2 / 3) * LW + (t2 % 3)) : 0) * HPS + 2 * ks2;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + off];
+            }
+            if (PREF || st + 1 < SPC) {
+                bnxt[0] = wp[0];
+                bnxt[1] = wp[64];
+                wp += 128;
+            }
+            if (PREF && st < NLOAD) pre[st] = halo_load(st, ck + 1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns)
+                    acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], acc[m][ns], 0, 0, 0);
+            if (st + 1 < SPC) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
+            }
+            if (PREF || st + 1 < SPC) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
+        }
+        if (PREF) {
+            if (SPC < NLOAD) {
+#pragma unroll
+                for (int it = SPC; it < NLOAD; ++it) pre[it] = halo_load(it, ck + 1);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+            __syncthreads();
+        }
+    };
+    for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
+    chunk(std::false_type{}, NCHUNK - 1);
+
+    // ---- epilogue (same structure as k_gemm_conv) ----
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
+    if (MODE == 2) {
+        const int kh = tap2 >> 1, kw = tap2 & 1;
+        const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
+            const int step = 2 * a.out_ps;
+            const bool rowok = y < a.Hc;
+            wide_store_h<32>(stg, lane, [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; }, xo,
+                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
+            const bool rowok = y < a.Hs;
+            wide_store_h<32>(stg, lane, [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); }, xo,
+                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
+        }
+        if (MODE == 1) {
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+            const int py = (y0 >> 1) + wave;
+            _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase;
+            const bool rowok = py < Hp;
+            wide_store_h<16>(stg, lane,
+                             [&](int ns, int q) {
+                                 const int r = (q & 1) * 2 + (q >> 1) * 4;
+                                 const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
+                                 return fmaxf(v + bias_v[ns], 0.f);
+                             },
+                             [&](int q) { return (q & 1) + 4 * (q >> 1) + 2 * h; },
+                             [&](int px) -> _Float16* { return (rowok && (x0 >> 1) + px < Wp) ? prow + (size_t)((x0 >> 1) + px) * COUT : nullptr; });
+        }
+    }
+}
+
+}  // namespace cid

@@ -233,6 +233,21 @@ class DenoiseGenerator(nn.Module):
             raise ValueError("conv_algo must be 'direct' or 'winograd'")
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
+    @property
+    def compute_dtype(self) -> str:
+        """"f32" (default: the reference's arithmetic) or "f16" (half storage between the first and last kernel,
+        fp16 MFMA with fp32 accumulators; BASELINE configs[4]).  Inputs/outputs keep their formats."""
+        d = ctypes.c_int()
+        _lib.check(self._cid, _lib.lib().cid_get_compute_dtype(self._cid, ctypes.byref(d)))
+        return "f16" if d.value == _lib.CID_DTYPE_F16 else "f32"
+
+    @compute_dtype.setter
+    def compute_dtype(self, name: str) -> None:
+        d = {"f32": _lib.CID_DTYPE_F32, "f16": _lib.CID_DTYPE_F16}.get(name)
+        if d is None:
+            raise ValueError("compute_dtype must be 'f32' or 'f16'")
+        _lib.check(self._cid, _lib.lib().cid_set_compute_dtype(self._cid, d))
+
     def timing_begin(self, max_forwards: int) -> None:
         """Arm per-launch HIP-event timing for the next `max_forwards` forwards (no per-forward sync)."""
         _lib.check(self._cid, _lib.lib().cid_timing_begin(self._cid, int(max_forwards)))

@@ -156,6 +156,18 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */
 enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD = 1 };
+
+/*
+ * Storage type of activations and weights between the first and the last kernel (BASELINE configs[4]):
+ *   CID_DTYPE_F32  the reference's arithmetic (default): fp32 storage, exact-fp32 MFMA
+ *   CID_DTYPE_F16  IEEE half storage, v_mfma_f32_32x32x16_f16 with fp32 accumulators, bias/ReLU/pool in fp32,
+ *                  one rounding to half per stored element; direct implicit GEMM for all ten GEMM layers.
+ * The caller-side tensors (cid_forward / cid_forward_ex) keep their formats; only the arena and the weight
+ * segments read change.  A different numerical contract from the reference's fp32 (tolerances: tests/).
+ */
+enum { CID_DTYPE_F32 = 0, CID_DTYPE_F16 = 1 };
+int cid_set_compute_dtype(cid_handle_t h, int dtype);
+int cid_get_compute_dtype(cid_handle_t h, int* dtype);
 int cid_set_conv_algo(cid_handle_t h, int algo);
 int cid_get_conv_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and

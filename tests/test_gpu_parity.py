@@ -283,3 +283,34 @@ def test_hip_graph_capture_and_replay(weight_sets):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_y, m(x2)) and not torch.equal(m(x1), m(x2))
+
+
+@pytest.mark.parametrize("wset,tol", [("default", 5e-4), ("hot", 2e-2)])
+def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
+    """BASELINE configs[4]: half storage + fp16 MFMA (fp32 accumulators) against the fp32 golden output.
+    A separate numerical contract: every stored activation and weight is rounded to half (2^-11 relative), so the
+    stated tolerance is relative to the activation scale: max|delta| <= 5e-4 at PyTorch-default weight scale
+    (outputs within +-0.07; BASELINE.md's 5e-3 bound with room to spare), <= 2e-2 on the He-gain weights
+    (activations up to 5, tanh to +-0.98); PSNR delta vs the fp32 reference is reported by the assertion message."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import psnr
+
+    g = np.load(os.path.join(golden_dir, f"full_{wset}_128.npz"))
+    x, clean, _ = synth.make_batch(2, 128, 128, 100)
+    m = cid.load(weight_sets[wset], device="cuda:0", strict=True)
+    m.compute_dtype = "f16"
+    assert m.compute_dtype == "f16"
+    y = _run(m, x)
+    err = float(np.abs(y - g["out"]).max())
+    dpsnr = abs(psnr(y, clean) - psnr(g["out"], clean))
+    assert err <= tol, (err, dpsnr)
+    assert dpsnr <= (0.01 if wset == "default" else 0.05), (err, dpsnr)
+    # ragged / crop path and the u8 front/back ends work in half storage too
+    gt = np.load(os.path.join(golden_dir, f"tiny_{wset}_13x18.npz"))
+    assert np.abs(_run(m, gt["x"]) - gt["out"]).max() <= tol
+    gu = np.load(os.path.join(golden_dir, f"u8_{wset}_32x40.npz"))
+    yu = m.forward_u8(torch.from_numpy(gu["noisy_u8"]).to("cuda:0")).cpu().numpy().astype(np.int16)
+    assert np.abs(yu - gu["out_u8"].astype(np.int16)).max() <= (1 if wset == "default" else 4)
+    m.compute_dtype = "f32"
+    assert np.abs(_run(m, x) - g["out"]).max() <= TOL
