@@ -69,7 +69,11 @@ template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
 __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int item) {
     constexpr int TRP = 32 / TC;                 // tile rows per pair
     constexpr int BTR = 2 * TRP;                 // tile rows per workgroup
-    constexpr int LW = 2 * TC + 2, LH = 2 * BTR + 2, LPIX = LW * LH;
+    constexpr int LW = 2 * TC + 2, LH = 2 * BTR + 2;
+    // LDS row stride in pixels.  TC=16 puts two tile rows in one 32-lane read; their slot offset (2 rows x LWS x 5
+    // slots) must be a multiple of 16 slots or the two half-rows collide in ds_read_b128's bank columns: 34 -> 40.
+    constexpr int LWS = (TC == 16) ? 40 : LW;
+    constexpr int LPIX = LWS * LH;
     constexpr int NROUND = (LPIX * WPS + 63) / 64;   // LDS-DMA wave-instructions (64 slots of 16 B) per buffer
     constexpr int RW = (NROUND + 3) / 4;             // rounds per wave
     constexpr int BUF = NROUND * 64;                 // f32x4 slots per LDS buffer (padded to whole rounds)
@@ -118,10 +122,10 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     // LDS pixel order inside a tile row: even columns first, then odd columns (column hx at (hx&1)*LW/2 + hx/2).
     // The 32 lanes of a read want columns 2*tc + c: with this order they are CONSECUTIVE pixels (stride 5 slots),
     // which ds_read_b128 serves conflict-free; in natural order they are 2 pixels apart = a 2-way bank conflict.
-    constexpr int HWD = LW / 2;
-    const int pbase = (2 * (pair * TRP + tr)) * LW + tc;
-    const int xb0 = (pbase + xrow0 * LW) * WPS + h, yb0 = (pbase + yrow0 * LW) * WPS + h;
-    const int xb1 = (pbase + xrow1 * LW) * WPS + h, yb1 = (pbase + yrow1 * LW) * WPS + h;
+    constexpr int HWD = LWS / 2;
+    const int pbase = (2 * (pair * TRP + tr)) * LWS + tc;
+    const int xb0 = (pbase + xrow0 * LWS) * WPS + h, yb0 = (pbase + yrow0 * LWS) * WPS + h;
+    const int xb1 = (pbase + xrow1 * LWS) * WPS + h, yb1 = (pbase + yrow1 * LWS) * WPS + h;
     auto col_off = [](int c) { return ((c & 1) * HWD + (c >> 1)) * WPS; };   // patch column c -> slot offset
 
     // ---- LDS-DMA sources.  Round j of a buffer fills slots [64j, 64j+64); wave w issues rounds w, w+4, ...
@@ -134,10 +138,10 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     for (int m = 0; m < RW; ++m) {
         const int s = (wave + 4 * m) * 64 + lane;
         const int p = s / WPS, c = s - p * WPS;
-        const int hy = p / LW, rem = p - hy * LW;
+        const int hy = p / LWS, rem = p - hy * LWS;
         const int plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;   // even/odd column planes (see above)
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = c < 4 && p < LPIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        const bool ok = c < 4 && p < LPIX && hx < LW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         ga[m] = ok ? inb + ((gy * a.Win + gx) * a.in_ps + c * 4) : a.zeros;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
