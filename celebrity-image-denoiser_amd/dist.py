@@ -3,7 +3,7 @@
 Every image is independent in the forward (no batch-norm or cross-sample op; reference
 backend/app.py:80-103), so the batch dimension is split contiguously over the ranks and the
 forward needs no communication.  The only collective is one broadcast of the packed weights blob
-(cid_packed_weights_bytes(), ~7.3 MB) from the rank that loaded the checkpoint:
+(cid_packed_weights_bytes(), ~30 MB: every kernel layout plus a reference-layout copy) from the rank that loaded the checkpoint:
 `torch.distributed.broadcast` on the "nccl" backend = RCCL over xGMI.  The reference has no
 distributed code; this is the build's own data-parallel driver.
 """
