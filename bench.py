@@ -233,12 +233,13 @@ def main():
         try:
             xh = torch.from_numpy(x_host).pin_memory()
             yh = torch.empty(tuple(y.shape), dtype=torch.float32).pin_memory()
+            yh.copy_(model(xh.to(dev, non_blocking=True)), non_blocking=True)   # untimed: first touch of the pinned buffers
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(5):
                 yh.copy_(model(xh.to(dev, non_blocking=True)), non_blocking=True)
             torch.cuda.synchronize(dev)
-            res["pcie_inclusive"] = {"images_per_sec": round(3 * B / (time.perf_counter() - t1), 1),
+            res["pcie_inclusive"] = {"images_per_sec": round(5 * B / (time.perf_counter() - t1), 1),
                                      "note": "per step: H2D 50 MB fp32 NCHW + forward + D2H 50 MB, pinned host buffers, rank 0 only"}
         except Exception as e:  # pragma: no cover
             res["pcie_inclusive"] = {"error": str(e)[:200]}
