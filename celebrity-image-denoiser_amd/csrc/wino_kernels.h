@@ -249,16 +249,22 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
             if (have_next_unit) read_cols(xq, yq, nbuf, nk, 0);
             const bool refill = !(ABLATE & 2) && ((k < 2) || decltype(has_next_tag)::value);
             const f32x4* bp = b_ptr(ck * 4 + k + 2);
+            // hipcc otherwise sinks the LDS reads of the next unit's A operand to the END of this unit (shorter live
+            // ranges) and the whole read -> transform chain lands between two units, in front of the next MFMA.
+            // The scheduling fences pin: reads first, transforms spread under the four MFMA groups.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (have_next_unit) {
+                    if (e == 1) { make_t(t, xq, yq, nk, 0); read_cols(xq, yq, nbuf, nk, 2); }
+                    if (e == 2) { make_t(t, xq, yq, nk, 2); vnxt[0] = t[0] - t[2]; vnxt[1] = t[1] + t[2]; }
+                    if (e == 3) { vnxt[2] = t[2] - t[1]; vnxt[3] = t[1] - t[3]; }
+                }
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][e][b], acc[u][b], 0, 0, 0);
                 if (refill) bq[k & 1][e] = bp[e * 64];
-                if (have_next_unit) {
-                    if (e == 0) { make_t(t, xq, yq, nk, 0); read_cols(xq, yq, nbuf, nk, 2); }
-                    if (e == 1) { make_t(t, xq, yq, nk, 2); make_v(vnxt, t); }
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (have_next_unit) {
 #pragma unroll
