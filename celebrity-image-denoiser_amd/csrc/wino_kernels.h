@@ -129,11 +129,14 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     auto col_off = [](int c) { return ((c & 1) * HWD + (c >> 1)) * WPS; };   // patch column c -> slot offset
 
     // ---- LDS-DMA sources.  Round j of a buffer fills slots [64j, 64j+64); wave w issues rounds w, w+4, ...
-    // Lane l of round j owns slot s = 64j + l = pixel s/5, 16-byte group s%5 (group 4 = pad).  Its source is
-    // the pixel's 4 channels of the current chunk, or the zero page (padding of the convolution, pad slots,
-    // slots past the tile); both advance by 64 bytes per chunk, so one 64-bit add per round per chunk.
+    // Lane l of round j owns slot s = 64j + l = pixel s/5, 16-byte group s%5 (group 4 = pad).  The source is a
+    // raw buffer over this image: a lane's 32-bit offset addresses its pixel's first 4 channels, the chunk is a
+    // scalar offset, and lanes that must deliver zeros (padding of the convolution, pad slots, slots past the
+    // tile) carry an out-of-range offset — the buffer range check makes the DMA write zeros for them.  No vector
+    // ALU work per chunk (VALU instructions beside the MFMA stream cost matrix-pipe time: tools/mix_bench).
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    const float* ga[RW];
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
+    unsigned voff[RW];
 #pragma unroll
     for (int m = 0; m < RW; ++m) {
         const int s = (wave + 4 * m) * 64 + lane;
@@ -142,42 +145,40 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
         const int plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;   // even/odd column planes (see above)
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = c < 4 && p < LPIX && hx < LW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        ga[m] = ok ? inb + ((gy * a.Win + gx) * a.in_ps + c * 4) : a.zeros;
+        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 4) * 4) : 0x7ffffff0u;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
-    auto dma_rounds = [&](int buf, int m0, int m1) {   // issue rounds [m0, m1) of this wave into buffer `buf`, advance sources
+    auto dma_rounds = [&](int buf, int m0, int m1, int ck) {   // rounds [m0, m1) of this wave, chunk ck -> buffer `buf`
+        const int soff = ck * (WK * 4);
 #pragma unroll
         for (int m = m0; m < m1; ++m) {
             if (wave + 4 * m < NROUND) {               // wave-uniform
                 const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ga[m]), "s"(dst) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
             }
-            ga[m] += WK;
         }
     };
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][b][r] = 0.f;
+    f32x16 acc[2][4];   // first written by the zero-C MFMAs of chunk 0 (no initialisation pass)
 
-    // U stream of this wave: unit (ck, g2, u) is 4 quads of 1 KiB at ((ck*2+g2)*4 + 2*half+u)*4*64 f32x4; quad e
-    // holds, for k-step e, the four positions b:  [nb][chunk][round][a][e][lane][b].
-    const f32x4* up = reinterpret_cast<const f32x4*>(a.u) + ((size_t)nb * NCHUNK * 2 * 16 + 2 * half * 4) * 64 + lane;
-    auto b_ptr = [&](int gunit) -> const f32x4* {          // gunit = ck*4 + g2*2 + u, this wave's unit counter
-        return up + ((size_t)((gunit >> 1) * 4 + (gunit & 1)) * 4) * 64;
+    // U stream of this wave: unit (ck, g2, u), k-step e is the 1 KiB quad at ((ck*2+g2)*16 + (2*half+u)*4 + e)*1024 bytes
+    // of this column block; [nb][chunk][round][a][e][lane][b].  Raw buffer loads: lane offset in a VGPR once, everything
+    // else scalar.
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, CIN * COUT * 16 * 4, 0x00020000);
+    const int ubase = (nb * NCHUNK * 2 * 16 + 2 * half * 4) * 1024;   // bytes, wave-uniform
+    const int ulane = lane * 16;
+    auto b_load = [&](int gunit, int e) -> f32x4 {          // gunit = ck*4 + g2*2 + u, this wave's unit counter
+        const int soff = ubase + (((gunit >> 1) * 4 + (gunit & 1)) * 4 + e) * 1024;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, soff, 0));
     };
 
     // ---- prologue: chunk 0 -> LDS buffer 0 by DMA; B of units 0 and 1 ----
-    if (!(ABLATE & 32)) dma_rounds(0, 0, RW);
+    if (!(ABLATE & 32)) dma_rounds(0, 0, RW, 0);
     f32x4 bq[2][4];                                        // ring: unit k uses bq[k&1][e]
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[d][e] = b_ptr(d)[e * 64];
+        for (int e = 0; e < 4; ++e) bq[d][e] = b_load(d, e);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to hipcc's own wait counting
     __syncthreads();
 
@@ -234,21 +235,22 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     // One barrier, at the end of unit 2, behind `s_waitcnt vmcnt(8)`: the eight B refills of units 1 and 2 are
     // the only vector-memory operations younger than the last DMA, so at most 8 outstanding means every DMA
     // of this wave has landed; past the barrier every wave's has, and nobody reads this buffer again.
-    auto chunk = [&](auto has_next_tag, int ck) {
+    auto chunk = [&](auto first_tag, auto has_next_tag, auto parity_tag, int ck) {
+        constexpr bool FIRST = decltype(first_tag)::value;         // chunk 0: accumulators start from a zero C operand
         constexpr bool NEXT = decltype(has_next_tag)::value && !(ABLATE & 1);
-        const int cur = (ABLATE & 1) ? 0 : (ck & 1) * BUF;
-        const int nxt = (ABLATE & 1) ? 0 : BUF - cur;
+        constexpr int PAR = decltype(parity_tag)::value ? 1 : 0;   // LDS buffer of this chunk, compile-time: immediates
+        constexpr int cur = (ABLATE & 1) ? 0 : PAR * BUF;
+        constexpr int nxt = (ABLATE & 1) ? 0 : BUF - cur;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int u = k & 1;
             const bool have_next_unit = ((k < 3) || decltype(has_next_tag)::value) && !(ABLATE & 4);
             const int nbuf = (k < 3) ? cur : nxt, nk = (k + 1) & 3;
             f32x4 xq[2], yq[2], t[4];
-            if (NEXT && k == 0) dma_rounds((ck + 1) & 1, 0, RW / 2);
-            if (NEXT && k == 1) dma_rounds((ck + 1) & 1, RW / 2, RW);
+            if (NEXT && k == 0) dma_rounds(1 - PAR, 0, RW / 2, ck + 1);
+            if (NEXT && k == 1) dma_rounds(1 - PAR, RW / 2, RW, ck + 1);
             if (have_next_unit) read_cols(xq, yq, nbuf, nk, 0);
             const bool refill = !(ABLATE & 2) && ((k < 2) || decltype(has_next_tag)::value);
-            const f32x4* bp = b_ptr(ck * 4 + k + 2);
             // hipcc otherwise sinks the LDS reads of the next unit's A operand to the END of this unit (shorter live
             // ranges) and the whole read -> transform chain lands between two units, in front of the next MFMA.
             // The scheduling fences pin: reads first, transforms spread under the four MFMA groups.
@@ -261,9 +263,15 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
                     if (e == 3) { vnxt[2] = t[2] - t[1]; vnxt[3] = t[1] - t[3]; }
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][e][b], acc[u][b], 0, 0, 0);
-                if (refill) bq[k & 1][e] = bp[e * 64];
+                for (int b = 0; b < 4; ++b) {
+                    if (FIRST && k < 2 && e == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][e][b], zero, 0, 0, 0);
+                    } else {
+                        acc[u][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[(ABLATE & 2) ? 0 : (k & 1)][e][b], acc[u][b], 0, 0, 0);
+                    }
+                }
+                if (refill) bq[k & 1][e] = b_load(ck * 4 + k + 2, e);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (have_next_unit) {
@@ -277,8 +285,15 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
-    chunk(std::false_type{}, NCHUNK - 1);
+    static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
+    chunk(std::true_type{}, std::true_type{}, std::false_type{}, 0);
+    chunk(std::false_type{}, std::true_type{}, std::true_type{}, 1);
+    for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
+        chunk(std::false_type{}, std::true_type{}, std::false_type{}, ck);
+        chunk(std::false_type{}, std::true_type{}, std::true_type{}, ck + 1);
+    }
+    chunk(std::false_type{}, std::true_type{}, std::false_type{}, NCHUNK - 2);
+    chunk(std::false_type{}, std::false_type{}, std::true_type{}, NCHUNK - 1);
 
     // ---- output transform.  m'[u][b'] = sum_b M[a][b] A[b][b'] for the two rows of this wave ----
     // A^T = [[1,1,1,0],[0,1,-1,-1]]; partial P[a'][b'] = sum over own rows a of A^T[a'][a] m'[a][b']
