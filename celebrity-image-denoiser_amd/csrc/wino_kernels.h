@@ -208,10 +208,13 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = t[c];
         } else {
-            v[0] = t[0] - t[2];
-            v[1] = t[1] + t[2];
-            v[2] = t[2] - t[1];
-            v[3] = t[1] - t[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // element-wise on purpose: whole-vector +/- lowers to v_pk_add_f32, which costs
+                v[0][e] = t[0][e] - t[2][e];   // the matrix pipe ~2.6x a plain VALU op (tools/mix_bench)
+                v[1][e] = t[1][e] + t[2][e];
+                v[2][e] = t[2][e] - t[1][e];
+                v[3][e] = t[1][e] - t[3][e];
+            }
         }
     };
 
@@ -259,8 +262,15 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
             for (int e = 0; e < 4; ++e) {
                 if (have_next_unit) {
                     if (e == 1) { make_t(t, xq, yq, nk, 0); read_cols(xq, yq, nbuf, nk, 2); }
-                    if (e == 2) { make_t(t, xq, yq, nk, 2); vnxt[0] = t[0] - t[2]; vnxt[1] = t[1] + t[2]; }
-                    if (e == 3) { vnxt[2] = t[2] - t[1]; vnxt[3] = t[1] - t[3]; }
+                    if (e == 2) {
+                        make_t(t, xq, yq, nk, 2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[0][q] = t[0][q] - t[2][q]; vnxt[1][q] = t[1][q] + t[2][q]; }
+                    }
+                    if (e == 3) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[2][q] = t[2][q] - t[1][q]; vnxt[3][q] = t[1][q] - t[3][q]; }
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
