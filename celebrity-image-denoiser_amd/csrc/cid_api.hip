@@ -236,6 +236,7 @@ hipError_t launch_gemm(hipStream_t s, const float* blob, int layer, const float*
     a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
     const TileGrid g = tiles_for(N, Hc, Wc);
     a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     hipLaunchKernelGGL((k_gemm_conv<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
     return hipGetLastError();
@@ -247,6 +248,7 @@ hipError_t launch_wino_tc(hipStream_t s, const WinoArgs& base) {
     constexpr int BTR = 2 * (32 / TC);
     a.tiles_x = cdiv(a.Wc, 2 * TC); a.tiles_y = cdiv(a.Hc, 2 * BTR);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
     hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN)), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
@@ -262,6 +264,7 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
+    a.rcp_x = a.rcp_xy = 0;
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
     return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
@@ -309,6 +312,7 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
     const TileGrid g = tiles_for(N, Hc, Wc);
     a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
     return hipGetLastError();
@@ -324,6 +328,11 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         char m[128];
         std::snprintf(m, sizeof m, "cid_forward: input [%d,3,%d,%d] not accepted: N >= 1 and H, W >= 4 required (output size is too small)", N, H, W);
         return fail(h, CID_ERR_SHAPE, m);
+    }
+    {   // tile decode divides by multiply-high with 32-bit reciprocals: exact while (M tiles) x (tiles per image) < 2^32
+        const unsigned long long t0 = (unsigned long long)cdiv(W, TILE_W) * cdiv(H, TILE_H);
+        if ((unsigned long long)N * t0 * t0 >= (1ull << 32))
+            return fail(h, CID_ERR_SHAPE, "cid_forward: batch x image too large for one call (split the batch)");
     }
     const Plan p = make_plan(d);
     if (ws_bytes < p.total_bytes) return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace smaller than cid_workspace_bytes()");
@@ -353,6 +362,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
         STEP(launch_head(s, a, 8 * g.per_xcd, in_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
@@ -379,6 +389,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
         STEP(launch_tail(s, a, 8 * g.per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
 #undef STEP

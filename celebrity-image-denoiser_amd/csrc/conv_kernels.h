@@ -47,6 +47,7 @@ struct GemmConvArgs {
     int Hs, Ws;         // region stored to `out` (<= Hc, Wc) — the top-left crop of a skip tensor
     int out_ps, out_coff;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
 // 16-byte LDS slot of (tile pixel p, 4-channel group c in 0..7): pixels are padded from 8 to 9
@@ -69,6 +70,19 @@ __device__ __forceinline__ bool decode_block(int tiles_total, int tiles_per_xcd,
     return mt < tiles_total && slot / NB < tiles_per_xcd;
 }
 
+
+// M tile index -> (image, tile row, tile column).  A 32-bit integer division costs ~40 VALU instructions per operand
+// pair, and VALU instructions beside the matrix pipe are not free (tools/mix_bench): the host passes
+// rcp = ceil(2^32 / d) and the quotient is one multiply-high, exact while value * d < 2^32 (checked on the host).
+__host__ __device__ inline unsigned tile_rcp(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ void decode_tile(int mt, int tiles_x, int tiles_y, unsigned rcp_x, unsigned rcp_xy, int& n, int& ty, int& tx) {
+    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane(mt);
+    const unsigned txy = (unsigned)(tiles_x * tiles_y);
+    const unsigned nn = rcp_xy ? __umulhi(m, rcp_xy) : m;          // rcp == 0 encodes divisor 1
+    const unsigned rem = m - nn * txy;
+    const unsigned yy = rcp_x ? __umulhi(rem, rcp_x) : rem;
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (unsigned)tiles_x);
+}
 
 // ---- wide store tail -------------------------------------------------------------------------
 // An MFMA accumulator tile holds, per lane, ONE output channel and 16 pixels, so storing it
@@ -173,9 +187,8 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
-    const int tx = mt % a.tiles_x;
-    const int ty = (mt / a.tiles_x) % a.tiles_y;
-    const int n = mt / (a.tiles_x * a.tiles_y);
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
 
     const int tid = threadIdx.x;
@@ -358,6 +371,7 @@ struct HeadArgs {
     void* out;          // NHWC [N,H,W,64]: fp32, or (OUT_F16) half for the fp16-storage path
     int N, H, W;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
 // IN_U8: the caller's image is uint8 HWC (what PIL hands the reference); ToTensor (/255) and Normalize(0.5,0.5)
@@ -369,9 +383,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     static_assert(3 * PLANE <= 4 * WS_FLOATS, "lds");
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
-    const int tx = mt % a.tiles_x;
-    const int ty = (mt / a.tiles_x) % a.tiles_y;
-    const int n = mt / (a.tiles_x * a.tiles_y);
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
 
@@ -458,6 +471,7 @@ struct TailArgs {
     void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
     int N, H, W;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
 // OUT_U8: the reference's view transform and PIL conversion folded in: y*0.5+0.5, clamp to [0,1] (app.py:435),
@@ -472,9 +486,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
     static_assert(LP * ZS * sizeof(float) <= sizeof(lds), "z must fit where x was");
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
-    const int tx = mt % a.tiles_x;
-    const int ty = (mt / a.tiles_x) % a.tiles_y;
-    const int n = mt / (a.tiles_x * a.tiles_y);
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
 

@@ -30,6 +30,7 @@ struct GemmConvArgsH {
     int Hc, Wc, Hs, Ws;
     int out_ps, out_coff;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
 template <int CIN, int COUT, int MODE>
@@ -49,9 +50,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
 
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
-    const int tx = mt % a.tiles_x;
-    const int ty = (mt / a.tiles_x) % a.tiles_y;
-    const int n = mt / (a.tiles_x * a.tiles_y);
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
 

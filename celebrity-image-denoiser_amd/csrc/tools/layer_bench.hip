@@ -32,6 +32,7 @@ static Variant make(const char* name, int N, int H, int W, float* in, float* w, 
     a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
     a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     const int grid = 8 * a.tiles_per_xcd * NB;
     const double flops = 2.0 * CIN * COUT * (MODE == 2 ? 4 : 9) * (double)N * H * W;
@@ -48,6 +49,7 @@ static Variant makew(const char* name, int N, int H, int W, float* in, float* u,
     constexpr int BTR = 2 * (32 / TC);
     a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);
     a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
     const int grid = 8 * a.tiles_per_xcd * (COUT / WN) / ((ABLATE & 128) ? 2 : 1);
     const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;   // algorithmic (direct) FLOPs
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};

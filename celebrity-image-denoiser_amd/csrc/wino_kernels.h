@@ -43,6 +43,7 @@ struct WinoArgs {
     int Hc, Wc, Hs, Ws;
     int out_ps, out_coff;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
 // ABLATE (timing experiments only, csrc/tools/layer_bench.hip; results are wrong when non-zero):
@@ -87,9 +88,8 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
 
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb, item)) return;
-    const int tx = mt % a.tiles_x;
-    const int ty = (mt / a.tiles_x) % a.tiles_y;
-    const int n = mt / (a.tiles_x * a.tiles_y);
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * (2 * BTR), x0 = tx * (2 * TC);
 
     const int tid = threadIdx.x;
