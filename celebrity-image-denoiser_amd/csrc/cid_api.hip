@@ -58,7 +58,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, tab_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -77,7 +77,9 @@ struct BlobLayout {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
             raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
-        zeros_off = o; o += 1024;   // 4 KiB zero page: source of LDS-DMA lanes that must deliver 0 (never written)
+        zeros_off = o; o += 1024;   // 4 KiB of zeros (kept for ABI stability of the blob; the DMA zeros come from the range check)
+        tab_off[0] = o; o = align_up(o + wino_slot_table(32, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
+        tab_off[1] = o; o = align_up(o + wino_slot_table(16, nullptr), 64);
         total = o;
     }
 };
@@ -185,7 +187,11 @@ struct cid_handle_s {
     int algo = CID_ALGO_WINOGRAD;      // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
-    cid_handle_s() : staging(kBlob.total, 0.f) { std::memset(have, 0, sizeof(have)); }
+    cid_handle_s() : staging(kBlob.total, 0.f) {
+        std::memset(have, 0, sizeof(have));
+        wino_slot_table(32, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
+        wino_slot_table(16, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
+    }
 };
 
 namespace {
@@ -259,13 +265,14 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
                           float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
     if (algo == 0) return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
     WinoArgs a;
-    a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.zeros = blob + kBlob.zeros_off;
+    a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.slot_tab = nullptr;
     a.out = out; a.pool = pool;
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
+    a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
     return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
 

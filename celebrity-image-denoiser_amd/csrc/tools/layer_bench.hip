@@ -43,8 +43,15 @@ template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
 static Variant makew(const char* name, int N, int H, int W, float* in, float* u, float* bias, float* out, float* pool) {
     WinoArgs a{};
     a.in = in; a.u = u; a.bias = bias; a.out = out; a.pool = pool;
-    static float* zeros = dalloc(1024, 0.f);
-    a.zeros = zeros;
+    static unsigned* tabs[2] = {nullptr, nullptr};
+    const int ti = TC == 32 ? 0 : 1;
+    if (!tabs[ti]) {
+        std::vector<unsigned> h(wino_slot_table(TC, nullptr));
+        wino_slot_table(TC, h.data());
+        CK(hipMalloc(&tabs[ti], h.size() * 4));
+        CK(hipMemcpy(tabs[ti], h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    a.slot_tab = tabs[ti];
     a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
     constexpr int BTR = 2 * (32 / TC);
     a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);

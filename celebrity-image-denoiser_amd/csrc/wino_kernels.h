@@ -32,11 +32,25 @@ constexpr int WPS = 5;        // LDS slots (16 B) per pixel: 4 data + 1 pad
 constexpr int WN = 32;        // output channels per workgroup
 constexpr int WS32 = 36;      // staging row stride (floats) for 32-channel slabs
 
+// Host: the slot table of k_wino_conv<.., TC>: LDS slot s (16 B) of the raw halo tile -> packed (row, column, group).
+// Must mirror the kernel's LDS order: pixel = s/5 (4 data slots + 1 pad), rows of LWS pixels, even columns then odd.
+inline int wino_slot_table(int TC, unsigned* out /* may be null */) {
+    const int TRP = 32 / TC, BTR = 2 * TRP, LW = 2 * TC + 2, LH = 2 * BTR + 2, LWS = (TC == 16) ? 40 : LW, HWD = LWS / 2;
+    const int LPIX = LWS * LH, NROUND = (LPIX * WPS + 63) / 64;
+    if (out)
+        for (int s = 0; s < NROUND * 64; ++s) {
+            const int p = s / WPS, c = s - p * WPS;
+            const int hy = p / LWS, rem = p - hy * LWS, plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;
+            out[s] = (c < 4 && p < LPIX && hx < LW) ? ((unsigned)hy << 20 | (unsigned)hx << 8 | (unsigned)c) : ~0u;
+        }
+    return NROUND * 64;
+}
+
 struct WinoArgs {
     const float* in;    // NHWC [N, Hin, Win, in_ps]
     const float* u;     // packed U: [nb][chunk][round][a][e][lane][b]  (cid_api.hip pack_winograd_u)
     const float* bias;  // [COUT]
-    const float* zeros; // >= 4 KiB of zeros: source of every LDS-DMA lane that must deliver 0
+    const unsigned* slot_tab;   // per LDS slot of the raw tile: (row << 20 | column << 8 | channel group), ~0u = deliver zeros (host: wino_slot_table)
     float* out;         // [N, Hs, Ws, out_ps] (+ out_coff)
     float* pool;        // POOL: [N, Hc/2, Wc/2, COUT]
     int N, Hin, Win, in_ps;
@@ -139,13 +153,12 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     unsigned voff[RW];
 #pragma unroll
     for (int m = 0; m < RW; ++m) {
-        const int s = (wave + 4 * m) * 64 + lane;
-        const int p = s / WPS, c = s - p * WPS;
-        const int hy = p / LWS, rem = p - hy * LWS;
-        const int plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;   // even/odd column planes (see above)
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = c < 4 && p < LPIX && hx < LW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 4) * 4) : 0x7ffffff0u;
+        // slot -> (tile row, tile column, channel group) comes from a host-built table (the index arithmetic is ~20 VALU
+        // instructions per slot; one L2-resident load instead)
+        const unsigned e = (wave + 4 * m < NROUND) ? a.slot_tab[(wave + 4 * m) * 64 + lane] : ~0u;
+        const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
+        const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4) : 0x7ffffff0u;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_rounds = [&](int buf, int m0, int m1, int ck) {   // rounds [m0, m1) of this wave, chunk ck -> buffer `buf`
@@ -319,103 +332,127 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
         if (sum == 123.456f) a.out[tid] = sum;
         return;
     }
-    const float c01 = half ? 0.f : 1.f, c10 = half ? -1.f : 0.f, c11 = half ? -1.f : 1.f;
-    __syncthreads();                                    // raw tiles are dead: LDS becomes exchange + staging
-    float yrow[2][16];   // this wave's output row a' = half: columns b' = 0,1 of each tile
-    float pooled[16];
-    if (POOL) {
-        // the pooled value needs all four outputs of a tile: exchange both rows of the partial transform
-        f32x4* ex = lds + wave * (16 * 64);
+    // Two code versions, selected by a wave-uniform branch, so that everything that depends on which half of the
+    // rows this wave holds is a compile-time constant (no selects, no multiplies by 0/+-1).
+    //   half 0 holds rows a = 0,1:  P[0] = m'0 + m'1 (its own output row), P[1] = m'1        (the partner's)
+    //   half 1 holds rows a = 2,3:  P[0] = m'0       (the partner's),      P[1] = -(m'0+m'1) (its own row)
+    auto epilogue = [&](auto half_tag) {
+        constexpr bool H1 = decltype(half_tag)::value;
+        __syncthreads();                                    // raw tiles are dead: LDS becomes exchange + staging
+        float yrow[2][16];   // this wave's output row a' = half: columns b' = 0,1 of each tile
+        float pooled[16];
+        auto mprime = [&](int u, int r, float& m0, float& m1) {
+            m0 = acc[u][0][r] + acc[u][1][r] + acc[u][2][r];
+            m1 = acc[u][1][r] - acc[u][2][r] - acc[u][3][r];
+        };
+        if (POOL) {
+            // the pooled value needs all four outputs of a tile: exchange both rows of the partial transform
+            f32x4* ex = lds + wave * (16 * 64);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m00 = acc[0][0][r] + acc[0][1][r] + acc[0][2][r], m01 = acc[0][1][r] - acc[0][2][r] - acc[0][3][r];
-            const float m10 = acc[1][0][r] + acc[1][1][r] + acc[1][2][r], m11 = acc[1][1][r] - acc[1][2][r] - acc[1][3][r];
-            f32x4 p;
-            p[0] = __builtin_fmaf(c01, m10, m00);
-            p[1] = __builtin_fmaf(c01, m11, m01);
-            p[2] = c10 * m00 + c11 * m10;
-            p[3] = c10 * m01 + c11 * m11;
-            ex[r * 64 + lane] = p;
-            acc[0][0][r] = p[0]; acc[0][1][r] = p[1]; acc[0][2][r] = p[2]; acc[0][3][r] = p[3];
+            for (int r = 0; r < 16; ++r) {
+                float m00, m01, m10, m11;
+                mprime(0, r, m00, m01);
+                mprime(1, r, m10, m11);
+                f32x4 p;
+                if (!H1) { p[0] = m00 + m10; p[1] = m01 + m11; p[2] = m10; p[3] = m11; }
+                else     { p[0] = m00; p[1] = m01; p[2] = -(m00 + m10); p[3] = -(m01 + m11); }
+                ex[r * 64 + lane] = p;
+                acc[0][0][r] = p[0]; acc[0][1][r] = p[1]; acc[0][2][r] = p[2]; acc[0][3][r] = p[3];
+            }
+            __syncthreads();
+            const f32x4* exo = lds + (wave ^ 1) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 o = exo[r * 64 + lane];
+                // Y = (half 0's partial) + (half 1's partial), in that order on both waves: bit-identical Y
+                const float y00 = H1 ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0];
+                const float y01 = H1 ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1];
+                const float y10 = H1 ? o[2] + acc[0][2][r] : acc[0][2][r] + o[2];
+                const float y11 = H1 ? o[3] + acc[0][3][r] : acc[0][3][r] + o[3];
+                yrow[0][r] = fmaxf((H1 ? y10 : y00) + bias_v, 0.f);
+                yrow[1][r] = fmaxf((H1 ? y11 : y01) + bias_v, 0.f);
+                pooled[r] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias_v, 0.f);
+            }
+        } else {
+            // each half only needs the partner's partial of ITS output row: 8 bytes per value pair
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2* ex = reinterpret_cast<f32x2*>(lds) + wave * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m00, m01, m10, m11;
+                mprime(0, r, m00, m01);
+                mprime(1, r, m10, m11);
+                f32x2 give;
+                if (!H1) { give[0] = m10; give[1] = m11; acc[0][0][r] = m00 + m10; acc[0][1][r] = m01 + m11; }   // keep P[0]
+                else     { give[0] = m00; give[1] = m01; acc[0][0][r] = m00 + m10; acc[0][1][r] = m01 + m11; }   // keep -P[1]
+                ex[r * 64 + lane] = give;
+            }
+            __syncthreads();
+            const f32x2* exo = reinterpret_cast<const f32x2*>(lds) + (wave ^ 1) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x2 o = exo[r * 64 + lane];
+                // half 0: Y[0] = P0[0] + P1[0] = keep + o;   half 1: Y[1] = P0[1] + P1[1] = o + (-(m'0+m'1)) = o - keep
+                yrow[0][r] = fmaxf((H1 ? o[0] - acc[0][0][r] : acc[0][0][r] + o[0]) + bias_v, 0.f);
+                yrow[1][r] = fmaxf((H1 ? o[1] - acc[0][1][r] : acc[0][1][r] + o[1]) + bias_v, 0.f);
+            }
         }
-        __syncthreads();
-        const f32x4* exo = lds + (wave ^ 1) * (16 * 64);
+        __syncthreads();                                    // exchange area is dead: reuse as store staging
+        float* stg = reinterpret_cast<float*>(lds) + wave * (64 * WS32);
+        auto tile_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };   // D row = tile index of register r
+        constexpr int hrow = H1 ? 1 : 0;
+        {
+            // staged pixels 0..63 are, in order, the 2*TC pixels of this wave's output row (TC=16: of its two rows)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const f32x4 o = exo[r * 64 + lane];
-            // add in a fixed order (half 0's partial first) so both halves see bit-identical Y
-            const float y00 = half ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0];
-            const float y01 = half ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1];
-            const float y10 = half ? o[2] + acc[0][2][r] : acc[0][2][r] + o[2];
-            const float y11 = half ? o[3] + acc[0][3][r] : acc[0][3][r] + o[3];
-            yrow[0][r] = fmaxf((half ? y10 : y00) + bias_v, 0.f);
-            yrow[1][r] = fmaxf((half ? y11 : y01) + bias_v, 0.f);
-            pooled[r] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias_v, 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const int t = tile_of(r);
+                stg[(2 * t) * WS32 + i] = yrow[0][r];
+                stg[(2 * t + 1) * WS32 + i] = yrow[1][r];
+            }
+            wave_lds_fence();
+            // Interior tiles (workgroup-uniform test) store with a wave-uniform row pointer plus one per-lane offset,
+            // bumped by scalars: no per-pixel bounds or address arithmetic on the vector ALU.
+            const bool full = (y0 + 2 * BTR <= a.Hs) && (x0 + 2 * TC <= a.Ws);
+            if (full) {
+                const int lane_off = (lane >> 3) * a.out_ps + (lane & 7) * 4;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sp0 = it * 8;
+                    const int ttr = (sp0 >> 1) / TC, xin = sp0 - ttr * 2 * TC;     // compile-time after unrolling
+                    const int y = y0 + 2 * (pair * TRP + ttr) + hrow;
+                    float* rowp = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0 + xin) * a.out_ps + a.out_coff + nb * WN;   // uniform
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (sp0 + (lane >> 3)) * WS32 + (lane & 7) * 4);
+                    *reinterpret_cast<f32x4*>(rowp + lane_off) = v;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sp = it * 8 + (lane >> 3);
+                    const int t = sp >> 1, ttr = t / TC, ttc = t - ttr * TC;
+                    const int y = y0 + 2 * (pair * TRP + ttr) + hrow, x = x0 + 2 * ttc + (sp & 1);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + sp * WS32 + (lane & 7) * 4);
+                    if (y < a.Hs && x < a.Ws)
+                        *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + y) * a.Ws + x) * a.out_ps + a.out_coff + nb * WN + (lane & 7) * 4) = v;
+                }
+            }
+            wave_lds_fence();
         }
-    } else {
-        // each half only needs the partner's partial of ITS output row: 8 bytes per value pair
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2* ex = reinterpret_cast<f32x2*>(lds) + wave * (16 * 64);
+        if (POOL && !H1) {
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m00 = acc[0][0][r] + acc[0][1][r] + acc[0][2][r], m01 = acc[0][1][r] - acc[0][2][r] - acc[0][3][r];
-            const float m10 = acc[1][0][r] + acc[1][1][r] + acc[1][2][r], m11 = acc[1][1][r] - acc[1][2][r] - acc[1][3][r];
-            const float p00 = __builtin_fmaf(c01, m10, m00), p01 = __builtin_fmaf(c01, m11, m01);
-            const float p10 = c10 * m00 + c11 * m10, p11 = c10 * m01 + c11 * m11;
-            f32x2 give;                      // what the partner needs: half 0 gives row 1, half 1 gives row 0
-            give[0] = half ? p00 : p10;
-            give[1] = half ? p01 : p11;
-            ex[r * 64 + lane] = give;
-            acc[0][0][r] = half ? p10 : p00;  // what this wave keeps: its own output row
-            acc[0][1][r] = half ? p11 : p01;
+            for (int r = 0; r < 16; ++r) stg[tile_of(r) * WS32 + i] = pooled[r];
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int t = it * 8 + (lane >> 3), ttr = t / TC, ttc = t - ttr * TC;
+                const int py = (y0 >> 1) + pair * TRP + ttr, px = (x0 >> 1) + ttc;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + t * WS32 + (lane & 7) * 4);
+                if (py < Hp && px < Wp)
+                    *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + px) * COUT + nb * WN + (lane & 7) * 4) = v;
+            }
         }
-        __syncthreads();
-        const f32x2* exo = reinterpret_cast<const f32x2*>(lds) + (wave ^ 1) * (16 * 64);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const f32x2 o = exo[r * 64 + lane];
-            // fixed order (half 0's partial first), as in the POOL path
-            yrow[0][r] = fmaxf((half ? o[0] + acc[0][0][r] : acc[0][0][r] + o[0]) + bias_v, 0.f);
-            yrow[1][r] = fmaxf((half ? o[1] + acc[0][1][r] : acc[0][1][r] + o[1]) + bias_v, 0.f);
-        }
-    }
-    __syncthreads();                                    // exchange area is dead: reuse as store staging
-    float* stg = reinterpret_cast<float*>(lds) + wave * (64 * WS32);
-    auto tile_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };   // D row = tile index of register r
-    {
-        // staged pixel sp = 2*tile + b'  ->  output (y, x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = tile_of(r);
-            stg[(2 * t) * WS32 + i] = yrow[0][r];
-            stg[(2 * t + 1) * WS32 + i] = yrow[1][r];
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int sp = it * 8 + (lane >> 3);
-            const int t = sp >> 1, ttr = t / TC, ttc = t - ttr * TC;
-            const int y = y0 + 2 * (pair * TRP + ttr) + half, x = x0 + 2 * ttc + (sp & 1);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + sp * WS32 + (lane & 7) * 4);
-            if (y < a.Hs && x < a.Ws)
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + y) * a.Ws + x) * a.out_ps + a.out_coff + nb * WN + (lane & 7) * 4) = v;
-        }
-        wave_lds_fence();
-    }
-    if (POOL && half == 0) {
-        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stg[tile_of(r) * WS32 + i] = pooled[r];
-        wave_lds_fence();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int t = it * 8 + (lane >> 3), ttr = t / TC, ttc = t - ttr * TC;
-            const int py = (y0 >> 1) + pair * TRP + ttr, px = (x0 >> 1) + ttc;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + t * WS32 + (lane & 7) * 4);
-            if (py < Hp && px < Wp)
-                *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + px) * COUT + nb * WN + (lane & 7) * 4) = v;
-        }
-    }
+    };
+    if (half) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 }  // namespace cid
