@@ -204,29 +204,32 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
     for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
 
     // ---- this thread's pieces of the halo tile: piece `it` is LDS slot s = it*256 + tid ----
+    // Raw buffer loads over this image: the piece's byte offset sits in a VGPR for the whole kernel, the chunk is a
+    // scalar offset, and pieces outside the image (zero padding, ragged tiles) carry an out-of-range offset for which
+    // the buffer range check returns zeros — no address or masking work on the vector ALU per chunk.
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    int goff[NLOAD];
-    unsigned okmask = 0;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
+    unsigned goff[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
         const int s = it * THREADS + tid;
         const int p = s >> 3, c = s & 7;
         const int hy = p / LW, hx = p - hy * LW;
         const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-        const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        goff[it] = ok ? ((gy * a.Win + gx) * a.in_ps + c * 4) : 0;   // !ok: any valid address, value discarded
-        okmask |= (ok ? 1u : 0u) << it;
+        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 4) * 4) : 0x7ffffff0u;
     }
     const int wslot = lds_slot(tid >> 3, tid & 7);   // slot of piece 0; piece `it` is wslot + it*32*PSLOTS
-    auto halo_load = [&](int it, int ck) -> f32x4 {   // raw load; the padding mask is applied at store time
-        return *reinterpret_cast<const f32x4*>(inb + goff[it] + ck * KCHUNK);
+    auto halo_load = [&](int it, int ck) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * (KCHUNK * 4), 0));
     };
     auto halo_store = [&](int it, f32x4 v) {
-        if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the convolution
         if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[wslot + it * (THREADS / 8) * PSLOTS] = v;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];   // first written by the zero-C MFMAs of chunk 0
+
+    // A fragment base pixel of (row 2*wave+m, column i) inside the LDS tile, tap (0,0)    f32x16 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -236,7 +239,12 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 
     // A fragment base pixel of (row 2*wave+m, column i) inside the LDS tile, tap (0,0)
     const int pbase0 = (2 * wave) * LW + i;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w) + ((size_t)nb * NCHUNK * SPC) * 128 + lane;
+    // B fragments: step g (global over chunks) is the 2 KiB at (nb*NCHUNK*SPC + g)*2048 bytes; scalar offsets only
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * NOUT * TAPS * 4, 0x00020000);
+    const int wbase = nb * NCHUNK * SPC * 2048, wlane = lane * 16;
+    auto b_load = [&](int gstep, int ns) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, wbase + gstep * 2048 + ns * 1024, 0));
+    };
 
     f32x4 pre[NLOAD];
 #pragma unroll
@@ -244,15 +252,15 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
     f32x4 bq[NBUF][2];
 #pragma unroll
     for (int d = 0; d < DIST; ++d) {
-        bq[d][0] = wp[0];
-        bq[d][1] = wp[64];
-        wp += 128;
+        bq[d][0] = b_load(d, 0);
+        bq[d][1] = b_load(d, 1);
     }
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
     __syncthreads();
 
-    auto chunk = [&](auto pref_tag, int ck) {
+    auto chunk = [&](auto first_tag, auto pref_tag, int ck) {
+        constexpr bool FIRST = decltype(first_tag)::value;                  // chunk 0: accumulate onto a zero C operand
         constexpr bool PREF = decltype(pref_tag)::value && !(ABLATE & 1);   // another chunk follows
         f32x4 acur[2], anxt[2];
 #pragma unroll
@@ -266,9 +274,8 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
                 for (int m = 0; m < 2; ++m) anxt[m] = lds[lds_slot(pbase0 + m * LW + off, 2 * g2 + h)];
             }
             if ((decltype(pref_tag)::value || st + DIST < SPC) && !(ABLATE & 2)) {
-                bq[(st + DIST) % NBUF][0] = wp[0];
-                bq[(st + DIST) % NBUF][1] = wp[64];
-                wp += 128;
+                bq[(st + DIST) % NBUF][0] = b_load(ck * SPC + st + DIST, 0);
+                bq[(st + DIST) % NBUF][1] = b_load(ck * SPC + st + DIST, 1);
             }
             if (PREF && st < NLOAD) pre[st] = halo_load(st, ck + 1);
             constexpr int BSEL = (ABLATE & 2) ? 0 : -1;
@@ -277,8 +284,14 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int ns = 0; ns < 2; ++ns)
-                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bq[BSEL < 0 ? st % NBUF : 0][ns][e], acc[m][ns], 0, 0, 0);
+                    for (int ns = 0; ns < 2; ++ns) {
+                        if (FIRST && st == 0 && e == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bq[BSEL < 0 ? st % NBUF : 0][ns][e], zero, 0, 0, 0);
+                        } else {
+                            acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[m][e], bq[BSEL < 0 ? st % NBUF : 0][ns][e], acc[m][ns], 0, 0, 0);
+                        }
+                    }
             if (st + 1 < SPC && !(ABLATE & 4)) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
@@ -296,8 +309,10 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
             __syncthreads();
         }
     };
-    for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
-    chunk(std::false_type{}, NCHUNK - 1);
+    static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
+    chunk(std::true_type{}, std::true_type{}, 0);
+    for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
+    chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
 
     if (ABLATE & 8) {   // keep the accumulators alive without the store tail
         float sum = 0.f;
