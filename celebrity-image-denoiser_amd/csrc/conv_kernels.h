@@ -149,6 +149,50 @@ __device__ __forceinline__ void wide_store_h(float* stg, int lane, ValFn val, Pi
     wave_lds_fence();
 }
 
+// Interior-tile variants: the slab's pixels are `stride` floats (halfs) apart starting at the wave-uniform `base`, all in
+// range.  One per-lane offset for the whole tail, the rest is scalar: no per-pixel pointer or bounds arithmetic.
+template <int NPIX, typename ValFn, typename PixFn>
+__device__ __forceinline__ void wide_store_full(float* stg, int lane, ValFn val, PixFn pix, float* base, int stride) {
+    const int i = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NPIX / 2; ++k) {
+        const int px = pix(k);
+        stg[px * WS_STRIDE + i] = val(0, k);
+        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+    }
+    wave_lds_fence();
+    const int lane_off = (lane >> 4) * stride + (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < NPIX / 4; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * WS_STRIDE + (lane & 15) * 4);
+        *reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off) = v;
+    }
+    wave_lds_fence();
+}
+template <int NPIX, typename ValFn, typename PixFn>
+__device__ __forceinline__ void wide_store_h_full(float* stg, int lane, ValFn val, PixFn pix, _Float16* base, int stride) {
+    const int i = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NPIX / 2; ++k) {
+        const int px = pix(k);
+        stg[px * WS_STRIDE + i] = val(0, k);
+        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+    }
+    wave_lds_fence();
+    const int lane_off = (lane >> 3) * stride + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < NPIX / 8; ++it) {
+        const int px = it * 8 + (lane >> 3);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
+        *reinterpret_cast<f16x8*>(base + (size_t)(it * 8) * stride + lane_off) = v;
+    }
+    wave_lds_fence();
+}
+
 // MODE 0: 3x3 conv + bias + ReLU                      -> out (channel slice of a possibly wider buffer)
 // MODE 1: same, plus fused 2x2 max-pool                -> out (cropped region) and pool
 // MODE 2: 2x2 stride-2 transposed conv + bias (1 tap)  -> out, pixel-scattered; N index = tap*COUT + co
@@ -342,9 +386,12 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
             float* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
             const int step = 2 * a.out_ps;
             const bool rowok = y < a.Hc;
-            wide_store<32>(stg, lane,
-                           [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; }, xo,
-                           [&](int px) -> float* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+            auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
+            if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
+                wide_store_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
+            else
+                wide_store<32>(stg, lane, val, xo,
+                               [&](int px) -> float* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
         }
     } else {
 #pragma unroll
@@ -352,9 +399,12 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
             const int y = y0 + 2 * wave + m;
             float* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
             const bool rowok = y < a.Hs;
-            wide_store<32>(stg, lane,
-                           [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); }, xo,
-                           [&](int px) -> float* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
+            auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
+            if (y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws)
+                wide_store_full<32>(stg, lane, val, xo, orow + (size_t)x0 * a.out_ps, a.out_ps);
+            else
+                wide_store<32>(stg, lane, val, xo,
+                               [&](int px) -> float* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
         }
         if (MODE == 1) {
             // 2x2 max-pool, floor mode (nn.MaxPool2d(2,2), app.py:48,56): the four pixels of a
@@ -461,12 +511,18 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
         auto pix = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
         if (OUT_F16) {
             _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-            wide_store_h<32>(stg, lane, val, pix,
-                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+            if (y0 + TILE_H <= a.H && x0 + TILE_W <= a.W)
+                wide_store_h_full<32>(stg, lane, val, pix, orow + (size_t)x0 * 64, 64);
+            else
+                wide_store_h<32>(stg, lane, val, pix,
+                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
         } else {
             float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-            wide_store<32>(stg, lane, val, pix,
-                           [&](int px) -> float* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
+            if (y0 + TILE_H <= a.H && x0 + TILE_W <= a.W)
+                wide_store_full<32>(stg, lane, val, pix, orow + (size_t)x0 * 64, 64);
+            else
+                wide_store<32>(stg, lane, val, pix,
+                               [&](int px) -> float* { return (rowok && x0 + px < a.W) ? orow + (size_t)(x0 + px) * 64 : nullptr; });
         }
     }
 }
