@@ -577,28 +577,36 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail(const TailArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const size_t img_off = (size_t)n * a.H * a.W * 64;
+    // halo pieces by raw buffer loads over this image: per-piece byte offsets computed once, the 32-channel chunk is a
+    // scalar offset, out-of-image pieces carry an out-of-range offset (the range check returns the zero padding)
+    const size_t img_elems = (size_t)a.H * a.W * 64;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        IN_F16 ? (void*)(static_cast<const _Float16*>(a.in) + (size_t)n * img_elems) : (void*)(static_cast<const float*>(a.in) + (size_t)n * img_elems),
+        (short)0, (int)(img_elems * (IN_F16 ? 2 : 4)), 0x00020000);
+    unsigned goff[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+        const int s = it * THREADS + tid;
+        const int p = s >> 3, c = s & 7;
+        const int hy = p / LW, hx = p - hy * LW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        goff[it] = ok ? (unsigned)(((gy * a.W + gx) * 64 + c * 4) * (IN_F16 ? 2 : 4)) : 0x7ffffff0u;
+    }
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
         f32x4 stage[NLOAD];
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it) {
-            const int s = it * THREADS + tid;
-            const int p = s >> 3, c = s & 7;
-            const int hy = p / LW, hx = p - hy * LW;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = (s < NSLOT) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const int off = (ok ? ((gy * a.W + gx) * 64 + c * 4) : 0) + ck * KCHUNK;
-            f32x4 v;
             if (IN_F16) {
-                const f16x4 hv = *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(a.in) + img_off + off);
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, goff[it], ck * (KCHUNK * 2), 0);
+                const f16x4 hv = __builtin_bit_cast(f16x4, raw);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)hv[e];
+                for (int e = 0; e < 4; ++e) stage[it][e] = (float)hv[e];
             } else {
-                v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.in) + img_off + off);
+                stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * (KCHUNK * 4), 0));
             }
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            stage[it] = v;
         }
         if (ck > 0) __syncthreads();
 #pragma unroll
