@@ -63,23 +63,25 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
 
     // ---- this thread's pieces of the halo tile: piece `it` is data slot s = it*256 + tid (pixel s/4, slot s%4) ----
+    // raw buffer loads over this image (see k_gemm_conv): fixed per-piece byte offsets, scalar chunk offset, the range
+    // check supplies the zero padding
     const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    int goff[NLOAD];
-    unsigned okmask = 0;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
+    unsigned goff[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
         const int s = it * THREADS + tid;
         const int p = s >> 2, c = s & 3;
         const int hy = p / LW, hx = p - hy * LW;
         const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-        const bool ok = (s < NSLOT) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        goff[it] = ok ? ((gy * a.Win + gx) * a.in_ps + c * 8) : 0;
-        okmask |= (ok ? 1u : 0u) << it;
+        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 8) * 2) : 0x7ffffff0u;
     }
     const int wslot = (tid >> 2) * HPS + (tid & 3);   // piece `it` lands at wslot + it*64*HPS
-    auto halo_load = [&](int it, int ck) -> f32x4 { return *reinterpret_cast<const f32x4*>(inb + goff[it] + ck * KCHUNK); };
+    auto halo_load = [&](int it, int ck) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * (KCHUNK * 2), 0));
+    };
     auto halo_store = [&](int it, f32x4 v) {
-        if (!((okmask >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding (half 0 == all-zero bits)
         if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[wslot + it * 64 * HPS] = v;
     };
 
@@ -92,15 +94,18 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
             for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
 
     const int pbase0 = ((2 * wave) * LW + i) * HPS + h;   // slot of (row 2*wave, column i), tap (0,0), k-step 0
-    const f16x8* wp = reinterpret_cast<const f16x8*>(a.w) + ((size_t)nb * NCHUNK * SPC) * 128 + lane;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * NOUT * TAPS * 2, 0x00020000);
+    const int wbase = nb * NCHUNK * SPC * 2048, wlane = lane * 16;
+    auto b_load = [&](int gstep, int ns) -> f16x8 {   // step g is the 2 KiB at (nb*NCHUNK*SPC + g)*2048 bytes
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, wbase + gstep * 2048 + ns * 1024, 0));
+    };
 
     f32x4 pre[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
     f16x8 bcur[2], bnxt[2];
-    bcur[0] = wp[0];
-    bcur[1] = wp[64];
-    wp += 128;
+    bcur[0] = b_load(0, 0);
+    bcur[1] = b_load(0, 1);
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
     __syncthreads();
@@ -120,9 +125,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
                 for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + off];
             }
             if (PREF || st + 1 < SPC) {
-                bnxt[0] = wp[0];
-                bnxt[1] = wp[64];
-                wp += 128;
+                bnxt[0] = b_load(ck * SPC + st + 1, 0);
+                bnxt[1] = b_load(ck * SPC + st + 1, 1);
             }
             if (PREF && st < NLOAD) pre[st] = halo_load(st, ck + 1);
 #pragma unroll
@@ -163,8 +167,12 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
             _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
             const int step = 2 * a.out_ps;
             const bool rowok = y < a.Hc;
-            wide_store_h<32>(stg, lane, [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; }, xo,
-                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+            auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
+            if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
+                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
+            else
+                wide_store_h<32>(stg, lane, val, xo,
+                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
         }
     } else {
 #pragma unroll
@@ -172,8 +180,12 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
             const int y = y0 + 2 * wave + m;
             _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
             const bool rowok = y < a.Hs;
-            wide_store_h<32>(stg, lane, [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); }, xo,
-                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
+            auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
+            if (y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws)
+                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * a.out_ps, a.out_ps);
+            else
+                wide_store_h<32>(stg, lane, val, xo,
+                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
         }
         if (MODE == 1) {
             const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
