@@ -6,6 +6,7 @@ Public surface (mirrors what the reference's callers use, reference backend/app.
     load(path_or_state_dict)      -> DenoiseGenerator on the current GPU, weights loaded like load_state_safely
     denoise(model, image_batch)   -> image_batch
     denoise_u8(model, uint8 NHWC) -> uint8 NHWC (pre/post-processing fused into the first/last kernel)
+    HostPipeline(model).run(host_batches)   upload / forward / download overlapped on three HIP streams
 
 Everything numeric runs in hand-written HIP kernels behind the C ABI in include/cid.h
 (csrc/ -> libcid.so).  There is no CPU fallback: if the library is missing the calls raise.
@@ -21,6 +22,8 @@ _LAZY = {
     "get_padding": ("api", "get_padding"),
     "load_state_safely": ("api", "load_state_safely"),
     "psnr": ("metrics", "psnr"),
+    "HostPipeline": ("pipeline", "HostPipeline"),
+    "denoise_host_batches": ("pipeline", "denoise_host_batches"),
 }
 
 

@@ -131,7 +131,7 @@ class DenoiseGenerator(nn.Module):
         self._packed_sig = self._signature() if blob.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ forward
-    def _prepare(self, x: torch.Tensor):
+    def _prepare(self, x: torch.Tensor, out: torch.Tensor = None):
         if not isinstance(x, torch.Tensor):
             raise TypeError("DenoiseGenerator expects a torch.Tensor [N,3,H,W]")
         if x.dim() != 4 or x.shape[1] != 3:
@@ -160,20 +160,31 @@ class DenoiseGenerator(nn.Module):
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
         x = x.contiguous()
-        y = torch.empty((n, 3, ho.value, wo.value), dtype=torch.float32, device=x.device)
+        y = self._output(out, (n, 3, ho.value, wo.value), torch.float32, x.device)
         return x, y, n, h, w
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _output(out, shape, dtype, device) -> torch.Tensor:
+        """A fresh output tensor, or the caller's `out` after checking it is exactly what the kernels will write."""
+        if out is None:
+            return torch.empty(shape, dtype=dtype, device=device)
+        if tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != device or not out.is_contiguous():
+            raise RuntimeError(f"out= must be a contiguous {dtype} tensor of shape {list(shape)} on {device}, "
+                               f"got {out.dtype} {list(out.shape)} on {out.device}")
+        return out
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[N,3,H,W] fp32 in [-1,1] on the GPU -> [N,3,4*(H//4),4*(W//4)] fp32 in (-1,1).
-        Same contract as the reference forward (app.py:80-103); asynchronous on the current stream."""
-        x, y, n, h, w = self._prepare(x)
+        Same contract as the reference forward (app.py:80-103); asynchronous on the current stream.
+        `out=` (not in the reference) writes into a caller-owned tensor instead of allocating."""
+        x, y, n, h, w = self._prepare(x, out)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(self._cid, _lib.lib().cid_forward(self._cid, x.data_ptr(), y.data_ptr(), n, h, w,
                                                          self._ws.data_ptr(), self._ws.numel(), stream))
         return y
 
-    def forward_u8(self, images: torch.Tensor, out_u8: bool = True) -> torch.Tensor:
+    def forward_u8(self, images: torch.Tensor, out_u8: bool = True, out: torch.Tensor = None) -> torch.Tensor:
         """uint8 images [N,H,W,3] (PIL/numpy layout) on the GPU -> denoised images, with the reference's
         pre/post-processing folded into the first/last kernel (cid_forward_ex):
         input  (u8/255 - 0.5)/0.5                       app.py:401-405 (ToTensor + Normalize(0.5, 0.5))
@@ -181,11 +192,24 @@ class DenoiseGenerator(nn.Module):
         Returns uint8 [N,4*(H//4),4*(W//4),3], or with out_u8=False the fp32 NCHW tensor `forward` returns."""
         if not isinstance(images, torch.Tensor) or images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise RuntimeError("forward_u8 expects a uint8 tensor of shape [N,H,W,3]")
-        if images.device.type != "cuda":
-            raise RuntimeError("forward_u8 got a CPU tensor: this implementation is GPU-only; there is no CPU fallback")
-        if images.device != self._device():
-            raise RuntimeError(f"input on {images.device} but module parameters on {self._device()}")
-        n, h, w, _ = images.shape
+        return self.forward_fmt(images, out_u8=out_u8, out=out)
+
+    def forward_fmt(self, x: torch.Tensor, out_u8: bool, out: torch.Tensor = None) -> torch.Tensor:
+        """The forward with either caller-side format on either side (cid_forward_ex): `x` is uint8 [N,H,W,3] or
+        fp32 [N,3,H,W] (told apart by dtype), the result uint8 [N,Ho,Wo,3] (out_u8) or fp32 [N,3,Ho,Wo]."""
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise RuntimeError("expected a 4-d tensor: uint8 [N,H,W,3] or float32 [N,3,H,W]")
+        in_u8 = x.dtype == torch.uint8
+        if in_u8 and x.shape[3] != 3:
+            raise RuntimeError(f"expected uint8 images of shape [N,H,W,3], got {list(x.shape)}")
+        if not in_u8 and (x.dtype != torch.float32 or x.shape[1] != 3):
+            raise RuntimeError(f"expected float32 input of shape [N,3,H,W], got {x.dtype} {list(x.shape)}")
+        if x.device.type != "cuda":
+            raise RuntimeError("got a CPU tensor: this implementation is GPU-only; there is no CPU fallback")
+        if x.device != self._device():
+            raise RuntimeError(f"input on {x.device} but module parameters on {self._device()}")
+        n = x.shape[0]
+        h, w = (x.shape[1], x.shape[2]) if in_u8 else (x.shape[2], x.shape[3])
         L = _lib.lib()
         ho, wo = ctypes.c_int(), ctypes.c_int()
         if n < 1 or L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) != _lib.CID_OK:
@@ -193,18 +217,18 @@ class DenoiseGenerator(nn.Module):
         self.pack_weights()
         need = ctypes.c_size_t()
         _lib.check(self._cid, L.cid_workspace_bytes(n, h, w, ctypes.byref(need)))
-        if self._ws is None or self._ws.numel() < need.value or self._ws.device != images.device:
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != x.device:
             self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=images.device)
-        images = images.contiguous()
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        x = x.contiguous()
         if out_u8:
-            y = torch.empty((n, ho.value, wo.value, 3), dtype=torch.uint8, device=images.device)
+            y = self._output(out, (n, ho.value, wo.value, 3), torch.uint8, x.device)
         else:
-            y = torch.empty((n, 3, ho.value, wo.value), dtype=torch.float32, device=images.device)
-        stream = torch.cuda.current_stream(images.device).cuda_stream
-        with torch.cuda.device(images.device):
-            _lib.check(self._cid, L.cid_forward_ex(self._cid, images.data_ptr(), _lib.CID_FMT_U8_NHWC, y.data_ptr(),
-                                                   _lib.CID_FMT_U8_NHWC if out_u8 else _lib.CID_FMT_F32_NCHW,
+            y = self._output(out, (n, 3, ho.value, wo.value), torch.float32, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._cid, L.cid_forward_ex(self._cid, x.data_ptr(), _lib.CID_FMT_U8_NHWC if in_u8 else _lib.CID_FMT_F32_NCHW,
+                                                   y.data_ptr(), _lib.CID_FMT_U8_NHWC if out_u8 else _lib.CID_FMT_F32_NCHW,
                                                    n, h, w, self._ws.data_ptr(), self._ws.numel(), stream))
         return y
 

@@ -314,3 +314,57 @@ def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
     assert np.abs(yu - gu["out_u8"].astype(np.int16)).max() <= (1 if wset == "default" else 4)
     m.compute_dtype = "f32"
     assert np.abs(_run(m, x) - g["out"]).max() <= TOL
+
+
+def test_host_pipeline_matches_direct_calls(models):
+    """HostPipeline (upload / forward / download on three streams over two slots) returns, in order, exactly the
+    bytes the plain calls return: uint8 and fp32 batches, a ragged last batch, a change of image size mid-stream,
+    iterated denoising, and the pinned-view mode."""
+    from celebrity_image_denoiser_amd import HostPipeline
+
+    m = models["default"]
+    rng = np.random.default_rng(7)
+    u8 = [rng.integers(0, 256, size=(n, 24, 36, 3), dtype=np.uint8) for n in (5, 5, 5, 5, 3)]
+    u8 += [rng.integers(0, 256, size=(2, 17, 20, 3), dtype=np.uint8)]           # new image size: slots are refitted
+    want = [m.forward_u8(torch.from_numpy(b).to("cuda:0")).cpu().numpy() for b in u8]
+    pipe = HostPipeline(m, depth=2)
+    got = [t.numpy() for t in pipe.run(u8)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and g.dtype == np.uint8 and np.array_equal(g, w)
+    # pinned views (copy=False) are valid until the generator advances
+    for t, w in zip(pipe.run(u8[:4], copy=False), want[:4]):
+        assert t.is_pinned() and np.array_equal(t.numpy(), w)
+    # fp32 batches, three slots, two iterations == forward(forward(x))
+    f32 = [synth.make_batch(n, 20, 24, first_index=100 + 10 * i)[0] for i, n in enumerate((3, 3, 2))]
+    want2 = [_run(m, _run(m, b)) for b in f32]
+    got2 = [t.numpy() for t in HostPipeline(m, depth=3).run(f32, iterations=2)]
+    for g, w in zip(got2, want2):
+        assert np.array_equal(g, w)
+    # uint8 with iterations: the second pass consumes the fp32 output of the first (denoise_eavl_iter.py:93-96)
+    z = m.forward_u8(torch.from_numpy(u8[0]).to("cuda:0"), out_u8=False)
+    want3 = m.forward_fmt(z, out_u8=True).cpu().numpy()
+    assert np.array_equal(next(iter(pipe.run(u8[:1], iterations=2))).numpy(), want3)
+    with pytest.raises(RuntimeError):
+        list(pipe.run([np.zeros((1, 3, 3, 3), np.uint8)]))                      # H < 4: loud, like the reference
+    with pytest.raises(RuntimeError):
+        list(pipe.run([np.zeros((1, 8, 8), np.float32)]))
+
+
+def test_out_argument_and_mixed_formats(models):
+    """forward(x, out=) / forward_fmt(x, out_u8, out=) write into caller-owned tensors and refuse wrong ones."""
+    m = models["hot"]
+    x, _, noisy = synth.make_batch(2, 16, 20, first_index=40)
+    xd = torch.from_numpy(x).to("cuda:0")
+    y = m(xd)
+    buf = torch.empty_like(y)
+    assert m(xd, out=buf) is buf and torch.equal(buf, y)
+    with pytest.raises(RuntimeError):
+        m(xd, out=torch.empty((2, 3, 16, 24), device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        m(xd, out=torch.empty((2, 3, 16, 20), dtype=torch.float16, device="cuda:0"))
+    # fp32 in -> uint8 out equals uint8 in -> uint8 out when the fp32 input is the normalised uint8 image
+    img = torch.from_numpy(noisy).to("cuda:0")
+    a = m.forward_u8(img)
+    b = m.forward_fmt(torch.from_numpy(synth.normalize_u8(noisy)).to("cuda:0"), out_u8=True)
+    assert a.dtype == torch.uint8 and torch.equal(a, b)

@@ -147,3 +147,13 @@ def test_torch_free_checkpoint_reader(tmp_path):
         zf.writestr("archive/data.pkl", pickle.dumps(os.getcwd))
     with pytest.raises(pickle.UnpicklingError):
         ckpt.read_checkpoint(evil)
+
+
+def test_host_pipeline_refuses_cpu_model():
+    """The overlapped host pipeline is a GPU product path: a model that is not on a GPU is refused loudly."""
+    import celebrity_image_denoiser_amd as cid
+
+    with pytest.raises(RuntimeError, match="GPU"):
+        cid.HostPipeline(cid.DenoiseGenerator())
+    with pytest.raises(ValueError):
+        cid.HostPipeline(cid.DenoiseGenerator(), depth=1)
