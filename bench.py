@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--weights", default="default", choices=["default", "hot"])
-    ap.add_argument("--algo", default="winograd", choices=["winograd", "direct"],
+    ap.add_argument("--algo", default="winograd", choices=["winograd", "winograd64", "direct"],
                     help="algorithm of the eight 3x3 GEMM layers (both fp32; default Winograd F(2x2,3x3))")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 = the reference's arithmetic (the headline metric); f16 = BASELINE configs[4] (half storage, "

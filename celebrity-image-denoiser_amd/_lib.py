@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libcid.so")
 CID_OK = 0
 CID_NUM_PARAMS = 24
 CID_NUM_LAUNCHES = 12
-CID_ALGO_DIRECT, CID_ALGO_WINOGRAD = 0, 1
+CID_ALGO_DIRECT, CID_ALGO_WINOGRAD, CID_ALGO_WINOGRAD64 = 0, 1, 2
 CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
 CID_DTYPE_F32, CID_DTYPE_F16 = 0, 1
 

@@ -5,6 +5,7 @@
 #include "../../include/cid.h"
 #include "conv_kernels.h"
 #include "wino_kernels.h"
+#include "wino64_kernels.h"
 #include "conv_kernels_f16.h"
 
 #include <cstdio>
@@ -36,6 +37,11 @@ const char* kHalfKernelNames[NL] = {
     "k_gemm_conv_h<128, 256, 0>", "k_gemm_conv_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_gemm_conv_h<256, 128, 0>",
     "k_gemm_conv_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_gemm_conv_h<128, 64, 0>", "k_conv_tail",
 };
+const char* kWino64KernelNames[NL] = {
+    nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
+    "k_wino64_conv<128, 256, false,", "k_wino64_conv<256, 256, false,", nullptr, "k_wino64_conv<256, 128, false,",
+    "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
+};
 const char* kWinoKernelNames[NL] = {
     nullptr, "k_wino_conv<64, 64, true,", "k_wino_conv<64, 128, false,", "k_wino_conv<128, 128, true,",
     "k_wino_conv<128, 256, false,", "k_wino_conv<256, 256, false,", nullptr, "k_wino_conv<256, 128, false,",
@@ -58,7 +64,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, tab_off[2], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u2_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, tab_off[4], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -78,8 +84,14 @@ struct BlobLayout {
             raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
         zeros_off = o; o += 1024;   // 4 KiB of zeros (kept for ABI stability of the blob; the DMA zeros come from the range check)
-        tab_off[0] = o; o = align_up(o + wino_slot_table(32, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
-        tab_off[1] = o; o = align_up(o + wino_slot_table(16, nullptr), 64);
+        tab_off[0] = o; o = align_up(o + wino_slot_table(32, 2, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
+        tab_off[1] = o; o = align_up(o + wino_slot_table(16, 4, nullptr), 64);
+        tab_off[2] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // k_wino64_conv: half as many tile rows per workgroup
+        tab_off[3] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
+        for (int l = 0; l < NL; ++l) {   // U again, in k_wino64_conv's order
+            u2_off[l] = o;
+            if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 16, 64);
+        }
         total = o;
     }
 };
@@ -122,7 +134,8 @@ size_t ref_index(const LayerDef& L, int co, int ci, int kh, int kw) {
 // (co, ci)), in double, rounded once to fp32, laid out for wino_kernels.h:
 //   [nb = co/32][chunk = ci/16][round = (ci/8)%2][a][e][lane = 32*h + j][b],  ci = 16*chunk + 8*round + 4*h + e, co = 32*nb + j
 // (one 16-byte quad per lane = the four positions b of k-step e, so a quad's registers free up after 4 MFMAs)
-void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
+// dst2 (k_wino64_conv): [nb = co/64][chunk][round][a][nt = (co/32)%2][e][lane = 32*h + j][b]
+void pack_winograd_u(const LayerDef& L, const float* w, float* dst, float* dst2) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = L.cin / 16;
     for (int co = 0; co < L.cout; ++co)
@@ -136,6 +149,7 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
                 for (int b = 0; b < 4; ++b) {
                     const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
                     dst[((((((size_t)nb * nchunk + ck) * 2 + g2) * 4 + a) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
+                    dst2[(((((((size_t)(nb >> 1) * nchunk + ck) * 2 + g2) * 4 + a) * 2 + (nb & 1)) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
                 }
         }
 }
@@ -189,8 +203,10 @@ struct cid_handle_s {
     int tev_forwards = 0, tev_used = 0;
     cid_handle_s() : staging(kBlob.total, 0.f) {
         std::memset(have, 0, sizeof(have));
-        wino_slot_table(32, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
-        wino_slot_table(16, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
+        wino_slot_table(32, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
+        wino_slot_table(16, 4, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
+        wino_slot_table(32, 1, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[2]));
+        wino_slot_table(16, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[3]));
     }
 };
 
@@ -259,6 +275,17 @@ hipError_t launch_wino_tc(hipStream_t s, const WinoArgs& base) {
     return hipGetLastError();
 }
 
+template <int CIN, int COUT, bool POOL, int TC>
+hipError_t launch_wino64_tc(hipStream_t s, const WinoArgs& base) {
+    WinoArgs a = base;
+    constexpr int TRW = 32 / TC;
+    a.tiles_x = cdiv(a.Wc, 2 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
+    a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL((k_wino64_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN2)), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 // One 3x3 GEMM layer, by the handle's algorithm: MODE 0/1 of k_gemm_conv or Winograd.
 template <int CIN, int COUT, int MODE>
 hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer, const float* in, int Hin, int Win, int in_ps,
@@ -272,6 +299,11 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
+    if (algo == CID_ALGO_WINOGRAD64) {
+        a.u = blob + kBlob.u2_off[layer];
+        a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 2 : 3]);
+        return Wc > 32 ? launch_wino64_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino64_tc<CIN, COUT, MODE == 1, 16>(s, a);
+    }
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
     return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
@@ -456,7 +488,7 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         float* dst = h->staging.data() + kBlob.w_off[l];
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
         std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
-        if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l]);
+        if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l], h->staging.data() + kBlob.u2_off[l]);
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
@@ -615,12 +647,13 @@ const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
-    return (h && h->algo == 1 && kWinoKernelNames[i]) ? kWinoKernelNames[i] : kKernelNames[i];
+    if (h && h->algo == CID_ALGO_WINOGRAD64 && kWino64KernelNames[i]) return kWino64KernelNames[i];
+    return (h && h->algo == CID_ALGO_WINOGRAD && kWinoKernelNames[i]) ? kWinoKernelNames[i] : kKernelNames[i];
 }
 
 int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
-    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
+    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD && algo != CID_ALGO_WINOGRAD64) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
     return CID_OK;
 }

@@ -46,8 +46,8 @@ static Variant makew(const char* name, int N, int H, int W, float* in, float* u,
     static unsigned* tabs[2] = {nullptr, nullptr};
     const int ti = TC == 32 ? 0 : 1;
     if (!tabs[ti]) {
-        std::vector<unsigned> h(wino_slot_table(TC, nullptr));
-        wino_slot_table(TC, h.data());
+        std::vector<unsigned> h(wino_slot_table(TC, 2 * (32 / TC), nullptr));
+        wino_slot_table(TC, 2 * (32 / TC), h.data());
         CK(hipMalloc(&tabs[ti], h.size() * 4));
         CK(hipMemcpy(tabs[ti], h.data(), h.size() * 4, hipMemcpyHostToDevice));
     }

@@ -1,0 +1,320 @@
+// wino64_kernels.h — Winograd F(2x2,3x3) 3x3 convolution, second decomposition: 32 tiles x 64 output channels per
+// workgroup, one row of the transformed tile per wave.
+//
+// Same function, same arithmetic and the same summation order as k_wino_conv (wino_kernels.h: see there for the
+// algorithm, the LDS pixel order, the LDS-DMA and the B stream); what changes is who owns what:
+//   * k_wino_conv:   wave = 2 rows a x 4 positions b x ONE 32-channel column block; every A operand (a V value, built
+//                    with 2 VALU instructions) feeds one MFMA.
+//   * k_wino64_conv: wave = ONE row a (= its wave index) x 4 positions b x TWO 32-channel column blocks; every A
+//                    operand feeds two MFMAs.  Per MFMA that is half the transform VALU and LDS reads, and 2/3 of the
+//                    halo DMA (the workgroup's raw tile is 2*TRW+2 rows for TRW tile rows instead of 4*TRP+2 for 2*TRP).
+//     VALU instructions beside the MFMA stream cost matrix-pipe time beyond ~1 per MFMA (tools/mix_bench); this
+//     decomposition sits at 1.
+//   A unit = row a, 8 input channels, both column blocks = 32 MFMAs; a 16-channel chunk = 2 units.
+//   * B: 8 quads (column block nt, k-step e) per unit, each refilled for the NEXT unit right after its four MFMAs.
+//   * raw tile double-buffered; the DMA of chunk c+2 is issued at the start of unit 1 of chunk c (its buffer was last
+//     read during unit 0) and must have landed by the one barrier of chunk c+1, at the end of its unit 0: two units
+//     (>= 4096 cycles) of slack.
+//   * epilogue: the four waves exchange their column-transformed rows m'[a] through LDS; wave w then finishes column
+//     block w>>1, tiles 16*(w&1) .. +16: Y[0] = (m'0 + m'1) + m'2, Y[1] = m'1 - (m'2 + m'3) (the order k_wino_conv uses,
+//     so both kernels return the same bits), bias, ReLU, optional 2x2 max-pool, 16-byte stores via LDS staging.
+#pragma once
+#include "wino_kernels.h"
+
+namespace cid {
+
+constexpr int WN2 = 64;       // output channels per workgroup
+
+template <int CIN, int COUT, bool POOL, int TC>
+__global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
+    constexpr int TRW = 32 / TC;                 // tile rows per workgroup
+    constexpr int LW = 2 * TC + 2, LH = 2 * TRW + 2;
+    constexpr int LWS = (TC == 16) ? 40 : LW;    // see k_wino_conv: two tile rows in one 32-lane read
+    constexpr int LPIX = LWS * LH;
+    constexpr int NROUND = (LPIX * WPS + 63) / 64;
+    constexpr int RW = (NROUND + 3) / 4;
+    constexpr int BUF = NROUND * 64;
+    constexpr int NCHUNK = CIN / WK;
+    constexpr int NB = COUT / WN2;
+    constexpr int HWD = LWS / 2;
+    static_assert(CIN % WK == 0 && COUT % WN2 == 0 && (TC == 16 || TC == 32), "layer dims");
+    static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
+    constexpr int LDS_SLOTS_K = 4096;            // 64 KiB: 2 raw buffers, later the 4x4 exchange blocks, later store staging
+    static_assert(2 * BUF <= LDS_SLOTS_K && RW <= 8, "LDS budget");
+    __shared__ f32x4 lds[LDS_SLOTS_K];
+
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
+    const int y0 = ty * (2 * TRW), x0 = tx * (2 * TC);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row a of B^T d B this wave accumulates
+    const int i = lane & 31, h = lane >> 5;
+    const int tr = i / TC, tc = i - tr * TC;
+
+    const float bias_v = a.bias[nb * WN2 + (wave >> 1) * 32 + i];   // epilogue role of wave w: column block w>>1, tiles 16*(w&1)..+16
+
+    if (blockIdx.x < 2 * 256) {   // de-phase the two workgroups of a CU once (see k_wino_conv)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) {
+            for (int sl = 0; sl < NCHUNK / 2; ++sl) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+
+    // rows of the 4x4 input patch that feed row a of B^T d:  t = x + sgn*y
+    //   a=0: d0 - d2   a=1: d1 + d2   a=2: d2 - d1   a=3: d1 - d3
+    const int xrow = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
+    const int yrow = (wave == 0 || wave == 1) ? 2 : (wave == 2) ? 1 : 3;
+    const float sgn = (wave == 1) ? 1.f : -1.f;
+    const int pbase = (2 * tr) * LWS + tc;
+    const int xb = (pbase + xrow * LWS) * WPS + h, yb = (pbase + yrow * LWS) * WPS + h;
+    auto col_off = [](int c) { return ((c & 1) * HWD + (c >> 1)) * WPS; };
+
+    // ---- LDS-DMA sources (as k_wino_conv) ----
+    const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
+    unsigned voff[RW];
+#pragma unroll
+    for (int m = 0; m < RW; ++m) {
+        const unsigned e = (wave + 4 * m < NROUND) ? a.slot_tab[(wave + 4 * m) * 64 + lane] : ~0u;
+        const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
+        const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4) : 0x7ffffff0u;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
+    auto dma_chunk = [&](int buf, int ck) {
+        const int soff = ck * (WK * 4);
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            if (wave + 4 * m < NROUND) {               // wave-uniform
+                const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
+            }
+        }
+    };
+
+    f32x16 acc[2][4];   // [column block nt][position b]; first written by the zero-C MFMAs of chunk 0
+
+    // U stream of this wave: [nb][chunk][round g2][a][nt][e][lane][b]: unit (ck, g2) is 8 KiB, quad (nt, e) 1 KiB inside it
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, CIN * COUT * 16 * 4, 0x00020000);
+    const int ubase = (nb * NCHUNK * 2 * 4 + wave) * 8192;   // bytes, wave-uniform
+    const int ulane = lane * 16;
+    auto b_load = [&](int gunit, int q) -> f32x4 {          // gunit = ck*2 + g2, q = nt*4 + e
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, ubase + gunit * (4 * 8192) + q * 1024, 0));
+    };
+
+    // ---- prologue: chunks 0 and 1 -> both LDS buffers; B of unit 0 ----
+    dma_chunk(0, 0);
+    dma_chunk(1, 1);
+    f32x4 bq[2][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bq[q >> 2][q & 3] = b_load(0, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to hipcc's own wait counting
+    __syncthreads();
+
+    auto read_cols = [&](f32x4 (&xq)[2], f32x4 (&yq)[2], int bufbase, int g2, int c0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            xq[c] = lds[bufbase + xb + 2 * g2 + col_off(c0 + c)];
+            yq[c] = lds[bufbase + yb + 2 * g2 + col_off(c0 + c)];
+        }
+    };
+    auto make_t = [&](f32x4 (&t)[4], const f32x4 (&xq)[2], const f32x4 (&yq)[2], int c0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c0 + c][e] = __builtin_fmaf(sgn, yq[c][e], xq[c][e]);
+    };
+
+    f32x4 vcur[4], vnxt[4];
+    {
+        f32x4 xq[2], yq[2], t[4];
+        read_cols(xq, yq, 0, 0, 0);
+        make_t(t, xq, yq, 0);
+        read_cols(xq, yq, 0, 0, 2);
+        make_t(t, xq, yq, 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // element-wise on purpose (no v_pk_add_f32: tools/mix_bench)
+            vcur[0][e] = t[0][e] - t[2][e];
+            vcur[1][e] = t[1][e] + t[2][e];
+            vcur[2][e] = t[2][e] - t[1][e];
+            vcur[3][e] = t[1][e] - t[3][e];
+        }
+    }
+
+    // Chunk ck in LDS buffer PAR.  Unit k = 32 MFMAs (k-step e outer, column block nt, position b inner: eight
+    // independent accumulators in rotation); under them the A operand of the next unit is read and built, and each B
+    // quad is refilled for the next unit as soon as its four MFMAs have issued.
+    auto chunk = [&](auto first_tag, auto more_tag, auto dma_tag, auto parity_tag, int ck) {
+        constexpr bool FIRST = decltype(first_tag)::value;    // chunk 0: accumulators start from a zero C operand
+        constexpr bool MORE = decltype(more_tag)::value;      // a chunk ck+1 exists
+        constexpr bool DMA = decltype(dma_tag)::value;        // a chunk ck+2 exists: fetch it into this chunk's buffer
+        constexpr int PAR = decltype(parity_tag)::value ? 1 : 0;
+        constexpr int cur = PAR * BUF, nxt = BUF - cur;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool have_next_unit = (k == 0) || MORE;
+            const int nbuf = (k == 0) ? cur : nxt, ng2 = 1 - k;
+            f32x4 xq[2], yq[2], t[4];
+            // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
+            if (DMA && k == 1) dma_chunk(PAR, ck + 2);
+            if (have_next_unit) read_cols(xq, yq, nbuf, ng2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (have_next_unit) {
+                    if (e == 1) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
+                    if (e == 2) {
+                        make_t(t, xq, yq, 2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[0][q] = t[0][q] - t[2][q]; vnxt[1][q] = t[1][q] + t[2][q]; }
+                    }
+                    if (e == 3) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[2][q] = t[2][q] - t[1][q]; vnxt[3][q] = t[1][q] - t[3][q]; }
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (FIRST && k == 0 && e == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], zero, 0, 0, 0);
+                        } else {
+                            acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], acc[nt][b], 0, 0, 0);
+                        }
+                    }
+                    if (have_next_unit) bq[nt][e] = b_load(ck * 2 + k + 1, nt * 4 + e);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (have_next_unit) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vcur[b] = vnxt[b];
+            }
+            if (MORE && k == 0) {
+                // The DMA of chunk ck+1 was issued one chunk ago; the only vector-memory operations younger than it
+                // are the B refills of the previous unit (consumed above) and of this one: at most 8 outstanding
+                // means every DMA of this wave has landed; past the barrier every wave's has.
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __syncthreads();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    chunk(T{}, T{}, T{}, F{}, 0);
+    chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
+    for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
+        // chunk ck fetches ck+2 (exists: ck+2 < NCHUNK); chunk ck+1 fetches ck+3 (exists iff ck+3 < NCHUNK, true: NCHUNK even)
+        chunk(F{}, T{}, T{}, F{}, ck);
+        chunk(F{}, T{}, T{}, T{}, ck + 1);
+    }
+    chunk(F{}, T{}, F{}, F{}, NCHUNK - 2);
+    chunk(F{}, F{}, F{}, T{}, NCHUNK - 1);
+
+    // ---- output transform ----
+    // Four code versions selected by a wave-uniform switch, so that "is this my own row / my own block" is a
+    // compile-time fact (no selects).  Column transform of this wave's row: m'[nt][b'] (b' = 0,1);
+    // A^T = [[1,1,1,0],[0,1,-1,-1]].
+    auto epilogue = [&](auto wave_tag) {
+        constexpr int W = decltype(wave_tag)::value;
+        constexpr int NT_W = W >> 1, RH = W & 1;                // epilogue role: column block, tile half
+        __syncthreads();                                        // raw tiles are dead: LDS becomes the exchange area
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // exchange block (src row a, dst wave w): 8 registers x 64 lanes of f32x2 = 4 KiB at ((a*4 + w) * 512) f32x2
+        f32x2* ex = reinterpret_cast<f32x2*>(lds);
+        f32x2 own[8];                                           // this wave's own row for its own outputs
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                f32x2 m;
+                m[0] = acc[nt][0][r] + acc[nt][1][r] + acc[nt][2][r];
+                m[1] = acc[nt][1][r] - acc[nt][2][r] - acc[nt][3][r];
+                const int w = nt * 2 + (r >> 3);                // consumer of (column block nt, register half r>>3)
+                if (w == W) own[r & 7] = m;
+                else ex[(W * 4 + w) * 512 + (r & 7) * 64 + lane] = m;
+            }
+        __syncthreads();
+        float y[2][2][8];   // [output row a'][column b'][register]
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            f32x2 m[4];
+#pragma unroll
+            for (int arow = 0; arow < 4; ++arow) m[arow] = (arow == W) ? own[rr] : ex[(arow * 4 + W) * 512 + rr * 64 + lane];
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {   // the summation order of k_wino_conv: same bits from both kernels
+                y[0][bp][rr] = (m[0][bp] + m[1][bp]) + m[2][bp];
+                y[1][bp][rr] = m[1][bp] - (m[2][bp] + m[3][bp]);
+            }
+        }
+        __syncthreads();                                        // exchange area is dead: reuse as store staging
+        float* stg = reinterpret_cast<float*>(lds) + W * (64 * WS32);
+        // register rr of this wave is tile  T = 16*RH + (rr&3) + 8*(rr>>2) + 4*h  of the workgroup's 32
+        auto tl_of = [&](int rr) { return (rr & 3) + 8 * (rr >> 2) + 4 * h; };
+        float pooled[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            if (POOL) pooled[rr] = fmaxf(fmaxf(fmaxf(y[0][0][rr], y[0][1][rr]), fmaxf(y[1][0][rr], y[1][1][rr])) + bias_v, 0.f);
+#pragma unroll
+            for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp)
+                    stg[(ap * 32 + 2 * tl_of(rr) + bp) * WS32 + i] = fmaxf(y[ap][bp][rr] + bias_v, 0.f);
+        }
+        wave_lds_fence();
+        // staged pixel sp = a' * 32 + (2*tl + b'): the wave's 16 tiles are tile row WTR, tile columns WTC .. WTC+15
+        constexpr int WTR = (16 * RH) / TC, WTC = (16 * RH) % TC;
+        const int wy = y0 + 2 * WTR, wx = x0 + 2 * WTC;
+        const int cbase = a.out_coff + nb * WN2 + NT_W * 32;
+        const bool full = (y0 + 2 * TRW <= a.Hs) && (x0 + 2 * TC <= a.Ws);
+        if (full) {
+            const int lane_off = (lane >> 3) * a.out_ps + (lane & 7) * 4;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int ap = it >> 2, xin = (it & 3) * 8;       // compile-time
+                float* rowp = a.out + ((size_t)(n * a.Hs + wy + ap) * a.Ws + wx + xin) * a.out_ps + cbase;   // uniform
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 8 + (lane >> 3)) * WS32 + (lane & 7) * 4);
+                *reinterpret_cast<f32x4*>(rowp + lane_off) = v;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int yy = wy + (it >> 2), xx = wx + (it & 3) * 8 + (lane >> 3);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 8 + (lane >> 3)) * WS32 + (lane & 7) * 4);
+                if (yy < a.Hs && xx < a.Ws)
+                    *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + yy) * a.Ws + xx) * a.out_ps + cbase + (lane & 7) * 4) = v;
+            }
+        }
+        if (POOL) {
+            wave_lds_fence();
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) stg[tl_of(rr) * WS32 + i] = pooled[rr];
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int tl = it * 8 + (lane >> 3);
+                const int py = (y0 >> 1) + WTR, px = (x0 >> 1) + WTC + tl;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + tl * WS32 + (lane & 7) * 4);
+                if (py < Hp && px < Wp)
+                    *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + px) * COUT + nb * WN2 + NT_W * 32 + (lane & 7) * 4) = v;
+            }
+        }
+    };
+    switch (wave) {
+        case 0: epilogue(std::integral_constant<int, 0>{}); break;
+        case 1: epilogue(std::integral_constant<int, 1>{}); break;
+        case 2: epilogue(std::integral_constant<int, 2>{}); break;
+        default: epilogue(std::integral_constant<int, 3>{}); break;
+    }
+}
+
+}  // namespace cid

@@ -34,8 +34,9 @@ constexpr int WS32 = 36;      // staging row stride (floats) for 32-channel slab
 
 // Host: the slot table of k_wino_conv<.., TC>: LDS slot s (16 B) of the raw halo tile -> packed (row, column, group).
 // Must mirror the kernel's LDS order: pixel = s/5 (4 data slots + 1 pad), rows of LWS pixels, even columns then odd.
-inline int wino_slot_table(int TC, unsigned* out /* may be null */) {
-    const int TRP = 32 / TC, BTR = 2 * TRP, LW = 2 * TC + 2, LH = 2 * BTR + 2, LWS = (TC == 16) ? 40 : LW, HWD = LWS / 2;
+// BTR = tile rows per workgroup: 2*(32/TC) for k_wino_conv, 32/TC for k_wino64_conv.
+inline int wino_slot_table(int TC, int BTR, unsigned* out /* may be null */) {
+    const int LW = 2 * TC + 2, LH = 2 * BTR + 2, LWS = (TC == 16) ? 40 : LW, HWD = LWS / 2;
     const int LPIX = LWS * LH, NROUND = (LPIX * WPS + 63) / 64;
     if (out)
         for (int s = 0; s < NROUND * 64; ++s) {

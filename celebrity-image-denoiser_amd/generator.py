@@ -248,13 +248,13 @@ class DenoiseGenerator(nn.Module):
         """"winograd" (default; F(2x2,3x3) on MFMA) or "direct" (9-tap implicit GEMM) for the 3x3 GEMM layers."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
-        return "winograd" if a.value == _lib.CID_ALGO_WINOGRAD else "direct"
+        return {_lib.CID_ALGO_WINOGRAD: "winograd", _lib.CID_ALGO_WINOGRAD64: "winograd64"}.get(a.value, "direct")
 
     @conv_algo.setter
     def conv_algo(self, name: str) -> None:
-        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd": _lib.CID_ALGO_WINOGRAD}.get(name)
+        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd": _lib.CID_ALGO_WINOGRAD, "winograd64": _lib.CID_ALGO_WINOGRAD64}.get(name)
         if algo is None:
-            raise ValueError("conv_algo must be 'direct' or 'winograd'")
+            raise ValueError("conv_algo must be 'direct', 'winograd' or 'winograd64'")
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
     @property
