@@ -427,9 +427,10 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
-        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
+        tail_groups(a);
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
-        STEP(launch_tail(s, a, 8 * g.per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
+        STEP(launch_tail(s, a, 8 * a.groups_per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
 #undef STEP
     if (ev && hipEventRecord(ev[NL], s) != hipSuccess) return fail(h, CID_ERR_HIP, "hipEventRecord failed");
