@@ -198,7 +198,7 @@ struct cid_handle_s {
     const float* dev_blob = nullptr;
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
-    int algo = CID_ALGO_WINOGRAD;      // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3)
+    int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 / 2 = Winograd F(2x2,3x3), 32 / 64 channels per workgroup
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
     cid_handle_s() : staging(kBlob.total, 0.f) {

@@ -245,7 +245,8 @@ class DenoiseGenerator(nn.Module):
 
     @property
     def conv_algo(self) -> str:
-        """"winograd" (default; F(2x2,3x3) on MFMA) or "direct" (9-tap implicit GEMM) for the 3x3 GEMM layers."""
+        """"winograd64" (default; Winograd F(2x2,3x3) on MFMA, 64 output channels per workgroup), "winograd" (the same
+        arithmetic and bits, 32 output channels per workgroup) or "direct" (9-tap implicit GEMM) for the 3x3 GEMM layers."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
         return {_lib.CID_ALGO_WINOGRAD: "winograd", _lib.CID_ALGO_WINOGRAD64: "winograd64"}.get(a.value, "direct")

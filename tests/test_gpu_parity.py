@@ -187,7 +187,7 @@ def test_winograd_and_direct_agree(weight_sets):
 
     x, _, _ = synth.make_batch(4, 128, 128, first_index=1300)
     m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
-    assert m.conv_algo == "winograd"
+    assert m.conv_algo == "winograd64"   # the default
     yw = _run(m, x)
     m.conv_algo = "direct"
     yd = _run(m, x)
