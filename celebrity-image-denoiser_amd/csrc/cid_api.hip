@@ -369,7 +369,8 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         return fail(h, CID_ERR_SHAPE, m);
     }
     {   // tile decode divides by multiply-high with 32-bit reciprocals: exact while (M tiles) x (tiles per image) < 2^32
-        const unsigned long long t0 = (unsigned long long)cdiv(W, TILE_W) * cdiv(H, TILE_H);
+        // the finest tiling of any launch is k_wino64_conv's at full resolution: 2 rows x 64 columns per tile
+        const unsigned long long t0 = (unsigned long long)cdiv(W, 64) * cdiv(H, 2) + (unsigned long long)cdiv(W, TILE_W) * cdiv(H, TILE_H);
         if ((unsigned long long)N * t0 * t0 >= (1ull << 32))
             return fail(h, CID_ERR_SHAPE, "cid_forward: batch x image too large for one call (split the batch)");
     }
