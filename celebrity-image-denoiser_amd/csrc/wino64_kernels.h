@@ -25,7 +25,10 @@ namespace cid {
 
 constexpr int WN2 = 64;       // output channels per workgroup
 
-template <int CIN, int COUT, bool POOL, int TC>
+// ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue,
+// 2 B quads loaded once, 4 A operand built once, 8 no epilogue, 16 epilogue without the global stores, 32 no per-chunk
+// barrier, 64 no prologue DMA, 128 no de-phasing of the two workgroups of a CU.
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     constexpr int TRW = 32 / TC;                 // tile rows per workgroup
     constexpr int LW = 2 * TC + 2, LH = 2 * TRW + 2;
@@ -60,7 +63,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     if (blockIdx.x < 2 * 256) {   // de-phase the two workgroups of a CU once (see k_wino_conv)
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) {
+        // Measured on this kernel (tools/layer_bench): without the de-phasing 2.40 ms, with it 2.27 ms (upconv1.0 shape).
+        if ((hwid & 1u) && !(ABLATE & 128)) {   // bit 7 (experiment): no de-phasing
             for (int sl = 0; sl < NCHUNK / 2; ++sl) __builtin_amdgcn_s_sleep(127);
         }
     }
@@ -78,12 +82,22 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
     unsigned voff[RW];
+    {
+        // All RW table entries are requested before the first is used, and the offsets are formed without branches:
+        // a guarded load or a divergent `ok ? offset : sentinel` compiles to load -> wait -> branch -> next load, i.e.
+        // RW serialised memory latencies in every workgroup's prologue.  The table is padded to 4*RW rounds (host).
+        unsigned ent[RW];
 #pragma unroll
-    for (int m = 0; m < RW; ++m) {
-        const unsigned e = (wave + 4 * m < NROUND) ? a.slot_tab[(wave + 4 * m) * 64 + lane] : ~0u;
-        const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
-        const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4) : 0x7ffffff0u;
+        for (int m = 0; m < RW; ++m) ent[m] = a.slot_tab[(wave + 4 * m) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            const unsigned e = ent[m];
+            const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
+            const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+            const unsigned off = (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4);
+            const unsigned keep = ok ? 0xffffffffu : 0u;
+            voff[m] = (off & keep) | (0x7ffffff0u & ~keep);
+        }
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_chunk = [&](int buf, int ck) {
@@ -108,8 +122,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     };
 
     // ---- prologue: chunks 0 and 1 -> both LDS buffers; B of unit 0 ----
-    dma_chunk(0, 0);
-    dma_chunk(1, 1);
+    if (!(ABLATE & 64)) {   // bit 6 (experiment): no prologue DMA
+        dma_chunk(0, 0);
+        dma_chunk(1, 1);
+    }
     f32x4 bq[2][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) bq[q >> 2][q & 3] = b_load(0, q);
@@ -146,8 +162,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
         }
     }
 
-    // Chunk ck in LDS buffer PAR.  Unit k = 32 MFMAs (k-step e outer, column block nt, position b inner: eight
-    // independent accumulators in rotation); under them the A operand of the next unit is read and built, and each B
+    // Chunk ck in LDS buffer PAR.  Unit k = 32 MFMAs (column block nt outer, k-step e, position b inner); under them the A operand of the next unit is read and built, and each B
     // quad is refilled for the next unit as soon as its four MFMAs have issued.
     auto chunk = [&](auto first_tag, auto more_tag, auto dma_tag, auto parity_tag, int ck) {
         constexpr bool FIRST = decltype(first_tag)::value;    // chunk 0: accumulators start from a zero C operand
@@ -161,43 +176,45 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             const int nbuf = (k == 0) ? cur : nxt, ng2 = 1 - k;
             f32x4 xq[2], yq[2], t[4];
             // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
-            if (DMA && k == 1) dma_chunk(PAR, ck + 2);
-            if (have_next_unit) read_cols(xq, yq, nbuf, ng2, 0);
+            if (DMA && k == 1 && !(ABLATE & 1)) dma_chunk(PAR, ck + 2);
+            const bool build = have_next_unit && !(ABLATE & 4);
+            if (build) read_cols(xq, yq, nbuf, ng2, 0);
             __builtin_amdgcn_sched_barrier(0);
+            // 8 groups of four MFMAs, group g = (column block nt = g/4, k-step e = g%4): one column block's four k-steps
+            // first, i.e. the same four accumulators in rotation for 16 MFMAs (measured 1.5 % faster than alternating
+            // the column blocks; the per-accumulator summation order is the same either way).
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (have_next_unit) {
-                    if (e == 1) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
-                    if (e == 2) {
+            for (int g = 0; g < 8; ++g) {
+                const int nt = g >> 2, e = g & 3;
+                if (build) {
+                    if (g == 2) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
+                    if (g == 4) {
                         make_t(t, xq, yq, 2);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { vnxt[0][q] = t[0][q] - t[2][q]; vnxt[1][q] = t[1][q] + t[2][q]; }
                     }
-                    if (e == 3) {
+                    if (g == 6) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { vnxt[2][q] = t[2][q] - t[1][q]; vnxt[3][q] = t[1][q] - t[3][q]; }
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (FIRST && k == 0 && e == 0) {
-                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], zero, 0, 0, 0);
-                        } else {
-                            acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], acc[nt][b], 0, 0, 0);
-                        }
+                for (int b = 0; b < 4; ++b) {
+                    if (FIRST && k == 0 && e == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], zero, 0, 0, 0);
+                    } else {
+                        acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], acc[nt][b], 0, 0, 0);
                     }
-                    if (have_next_unit) bq[nt][e] = b_load(ck * 2 + k + 1, nt * 4 + e);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (have_next_unit && !(ABLATE & 2)) bq[nt][e] = b_load(ck * 2 + k + 1, nt * 4 + e);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (have_next_unit) {
+            if (build) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) vcur[b] = vnxt[b];
             }
-            if (MORE && k == 0) {
+            if (MORE && k == 0 && !(ABLATE & 32)) {   // bit 5 (experiment): no per-chunk barrier
                 // The DMA of chunk ck+1 was issued one chunk ago; the only vector-memory operations younger than it
                 // are the B refills of the previous unit (consumed above) and of this one: at most 8 outstanding
                 // means every DMA of this wave has landed; past the barrier every wave's has.
@@ -223,6 +240,17 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     // Four code versions selected by a wave-uniform switch, so that "is this my own row / my own block" is a
     // compile-time fact (no selects).  Column transform of this wave's row: m'[nt][b'] (b' = 0,1);
     // A^T = [[1,1,1,0],[0,1,-1,-1]].
+    if (ABLATE & 8) {   // keep the accumulators alive without the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[nt][b][r];
+        if (sum == 123.456f) a.out[tid] = sum;
+        return;
+    }
     auto epilogue = [&](auto wave_tag) {
         constexpr int W = decltype(wave_tag)::value;
         constexpr int NT_W = W >> 1, RH = W & 1;                // epilogue role: column block, tile half
@@ -275,7 +303,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
         const int wy = y0 + 2 * WTR, wx = x0 + 2 * WTC;
         const int cbase = a.out_coff + nb * WN2 + NT_W * 32;
         const bool full = (y0 + 2 * TRW <= a.Hs) && (x0 + 2 * TC <= a.Ws);
-        if (full) {
+        if (ABLATE & 16) {
+            // experiment: everything but the global stores
+        } else if (full) {
             const int lane_off = (lane >> 3) * a.out_ps + (lane & 7) * 4;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {

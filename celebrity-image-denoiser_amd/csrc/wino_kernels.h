@@ -37,14 +37,16 @@ constexpr int WS32 = 36;      // staging row stride (floats) for 32-channel slab
 // BTR = tile rows per workgroup: 2*(32/TC) for k_wino_conv, 32/TC for k_wino64_conv.
 inline int wino_slot_table(int TC, int BTR, unsigned* out /* may be null */) {
     const int LW = 2 * TC + 2, LH = 2 * BTR + 2, LWS = (TC == 16) ? 40 : LW, HWD = LWS / 2;
-    const int LPIX = LWS * LH, NROUND = (LPIX * WPS + 63) / 64;
+    // padded to 4 * RW rounds (RW = rounds per wave), so that every wave reads RW entries unconditionally: a guarded
+    // load compiles to load -> wait -> next load, i.e. RW serialised memory latencies in every workgroup's prologue
+    const int LPIX = LWS * LH, NROUND = (LPIX * WPS + 63) / 64, RW = (NROUND + 3) / 4;
     if (out)
-        for (int s = 0; s < NROUND * 64; ++s) {
+        for (int s = 0; s < 4 * RW * 64; ++s) {
             const int p = s / WPS, c = s - p * WPS;
             const int hy = p / LWS, rem = p - hy * LWS, plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;
-            out[s] = (c < 4 && p < LPIX && hx < LW) ? ((unsigned)hy << 20 | (unsigned)hx << 8 | (unsigned)c) : ~0u;
+            out[s] = (s < NROUND * 64 && c < 4 && p < LPIX && hx < LW) ? ((unsigned)hy << 20 | (unsigned)hx << 8 | (unsigned)c) : ~0u;
         }
-    return NROUND * 64;
+    return 4 * RW * 64;
 }
 
 struct WinoArgs {
@@ -152,14 +154,22 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
     unsigned voff[RW];
+    {
+        // All RW table entries are requested before the first is used, and the offsets are formed without branches:
+        // a guarded load or a divergent `ok ? offset : sentinel` compiles to load -> wait -> branch -> next load, i.e.
+        // RW serialised memory latencies in every workgroup's prologue.  The table is padded to 4*RW rounds (host).
+        unsigned ent[RW];
 #pragma unroll
-    for (int m = 0; m < RW; ++m) {
-        // slot -> (tile row, tile column, channel group) comes from a host-built table (the index arithmetic is ~20 VALU
-        // instructions per slot; one L2-resident load instead)
-        const unsigned e = (wave + 4 * m < NROUND) ? a.slot_tab[(wave + 4 * m) * 64 + lane] : ~0u;
-        const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
-        const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-        voff[m] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4) : 0x7ffffff0u;
+        for (int m = 0; m < RW; ++m) ent[m] = a.slot_tab[(wave + 4 * m) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            const unsigned e = ent[m];
+            const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
+            const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+            const unsigned off = (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4);
+            const unsigned keep = ok ? 0xffffffffu : 0u;
+            voff[m] = (off & keep) | (0x7ffffff0u & ~keep);
+        }
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_rounds = [&](int buf, int m0, int m1, int ck) {   // rounds [m0, m1) of this wave, chunk ck -> buffer `buf`
