@@ -388,3 +388,31 @@ def test_out_argument_and_mixed_formats(models):
     a = m.forward_u8(img)
     b = m.forward_fmt(torch.from_numpy(synth.normalize_u8(noisy)).to("cuda:0"), out_u8=True)
     assert a.dtype == torch.uint8 and torch.equal(a, b)
+
+
+def test_seeded_shape_sweep_against_cpu_oracle(models, weight_sets):
+    """Twelve seeded (N, H, W) draws with H, W in [4, 150] — tile boundaries of every kernel (32/64-pixel tile columns,
+    2/4/8-row tiles, the W <= 32 variants), odd sizes that exercise the crop path, single rows of tiles — against the
+    ATen oracle at the stated tolerance."""
+    from oracle import torch_oracle
+
+    rng = np.random.default_rng(20240607)
+    shapes = [(int(rng.integers(1, 4)), int(rng.integers(4, 151)), int(rng.integers(4, 151))) for _ in range(10)]
+    shapes += [(1, 33, 65), (2, 130, 31)]
+    for k, (n, h, w) in enumerate(shapes):
+        wset = "hot" if k % 2 else "default"
+        x, _, _ = synth.make_batch(n, h, w, first_index=2000 + 10 * k)
+        y = _run(models[wset], x)
+        ref = torch_oracle.forward(weight_sets[wset], x).numpy()
+        assert y.shape == ref.shape == (n, 3, 4 * (h // 4), 4 * (w // 4)), (n, h, w)
+        assert np.abs(y - ref).max() <= TOL, (n, h, w, float(np.abs(y - ref).max()))
+
+
+def test_full_size_translation_of_batch_order(models):
+    """Size-independent property at BASELINE config-2 size: permuting the images of a batch permutes the outputs,
+    bit for bit (tile -> workgroup assignment, XCD placement and tiles-per-workgroup grouping must not leak between images)."""
+    x, _, _ = synth.make_batch(40, 128, 128, first_index=3000)
+    perm = np.random.default_rng(5).permutation(40)
+    y = _run(models["default"], x)
+    yp = _run(models["default"], np.ascontiguousarray(x[perm]))
+    assert np.array_equal(yp, y[perm])
