@@ -258,6 +258,24 @@ def main():
                                                        "streams; u8 = uint8 HWC images both ways (12.6 MB each way per step)")
         except Exception as e:  # pragma: no cover
             res.setdefault("pcie_inclusive", {})["error"] = str(e)[:200]
+        # single-image latency, the reference server's request shape (app.py:406,433): eager (12 launches) vs one HIP-graph launch
+        try:
+            from celebrity_image_denoiser_amd import GraphedForward
+
+            x1 = x[:1].contiguous()
+            fast = GraphedForward(model, x1)
+            for fn, key in ((lambda: model(x1), "eager_ms"), (lambda: fast(x1), "hip_graph_ms")):
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(200):
+                    fn()
+                torch.cuda.synchronize(dev)
+                res.setdefault("latency_n1", {"shape": [1, 3, S, S]})[key] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
+            res["latency_n1"]["note"] = "mean over 200 back-to-back forwards of one image, host time incl. launch path; not `value`"
+        except Exception as e:  # pragma: no cover
+            res["latency_n1"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(res))

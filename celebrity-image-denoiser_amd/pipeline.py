@@ -160,3 +160,40 @@ def denoise_host_batches(model: DenoiseGenerator, batches: Iterable, iterations:
                          depth: int = 2) -> Optional[List[torch.Tensor]]:
     """Convenience: run a list/iterator of host batches through a HostPipeline and return the list of results."""
     return HostPipeline(model, depth=depth)(batches, iterations=iterations)
+
+
+class GraphedForward:
+    """One forward at a fixed shape, captured into a HIP graph: a replay is ONE launch instead of twelve.
+
+    The reference serves one image per request (backend/app.py:406,433): at N=1 the twelve kernel launches of a forward
+    are short, and the host-side launch path is a visible part of the latency.  `cid_forward` only enqueues kernels (no
+    allocation, no synchronisation), so it can be stream-captured once and replayed.
+
+        fast = GraphedForward(model, example)        # example: fp32 [N,3,H,W] or uint8 [N,H,W,3] on the GPU
+        y = fast(x)                                  # same shape/dtype as example; result as `model(x)` / `forward_u8(x)`
+
+    The result tensor is owned by the graph and overwritten by the next call (clone it to keep it)."""
+
+    def __init__(self, model: DenoiseGenerator, example: torch.Tensor):
+        if example.device.type != "cuda":
+            raise RuntimeError("GraphedForward needs a GPU tensor as the example (no CPU fallback)")
+        self.model = model
+        self.u8 = example.dtype == torch.uint8
+        self.static_in = example.clone().contiguous()
+        model.forward_fmt(self.static_in, out_u8=self.u8)        # packs weights, sizes the arena: nothing allocates in the capture
+        torch.cuda.synchronize(example.device)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(example.device)
+        side.wait_stream(torch.cuda.current_stream(example.device))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self.graph, stream=side):
+                self.static_out = model.forward_fmt(self.static_in, out_u8=self.u8)
+        torch.cuda.current_stream(example.device).wait_stream(side)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
+            raise RuntimeError(f"GraphedForward was captured for {self.static_in.dtype} {list(self.static_in.shape)} on "
+                               f"{self.static_in.device}, got {x.dtype} {list(x.shape)} on {x.device}")
+        self.static_in.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

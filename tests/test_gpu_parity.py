@@ -416,3 +416,22 @@ def test_full_size_translation_of_batch_order(models):
     y = _run(models["default"], x)
     yp = _run(models["default"], np.ascontiguousarray(x[perm]))
     assert np.array_equal(yp, y[perm])
+
+
+def test_graphed_forward_matches_eager(models):
+    """GraphedForward (one HIP-graph launch per forward) returns the bits of the eager call, for fp32 and uint8 inputs,
+    follows new input contents, and refuses other shapes loudly."""
+    from celebrity_image_denoiser_amd import GraphedForward
+
+    m = models["default"]
+    x, _, noisy = synth.make_batch(3, 24, 40, first_index=4000)
+    xd = [torch.from_numpy(x[i:i + 1]).to("cuda:0") for i in range(3)]
+    fast = GraphedForward(m, xd[0])
+    for t in xd:
+        assert torch.equal(fast(t), m(t))
+    ud = [torch.from_numpy(noisy[i:i + 1]).to("cuda:0") for i in range(3)]
+    fast8 = GraphedForward(m, ud[0])
+    for t in ud:
+        assert torch.equal(fast8(t), m.forward_u8(t))
+    with pytest.raises(RuntimeError):
+        fast(torch.zeros((2, 3, 24, 40), device="cuda:0"))
