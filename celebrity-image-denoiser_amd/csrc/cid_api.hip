@@ -104,7 +104,8 @@ const BlobLayout kBlob;
 size_t packed_index(const LayerDef& L, int co, int ci, int kh, int kw) {
     switch (L.kind) {
         case HEAD: {
-            const int k = ci * 9 + kh * 3 + kw, s = k >> 1, h = k & 1;
+            int s, h;
+            head_step_of(ci * 9 + kh * 3 + kw, s, h);   // the head's K order (conv_kernels.h head_step)
             return (size_t)((co >> 5) * 14 + s) * 64 + h * 32 + (co & 31);
         }
         case TAIL: {   // B[k = ci][col = 3*tap + co] of the tail's 64 x 32 product

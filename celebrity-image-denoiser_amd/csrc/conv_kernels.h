@@ -442,6 +442,27 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 // Head: down1[0] = Conv2d(3, 64, 3, padding=1) + ReLU  (app.py:43-44).  Reads the caller's NCHW
 // input directly (the NCHW -> NHWC change of layout is folded into this kernel), K = 27 padded
 // to 28 = 14 MFMA k-steps; memory-bound on its 64-channel NHWC output.
+// K order of the head's 14 MFMA steps.  Step s multiplies element k0(s) on lanes h=0 and k1(s) on lanes h=1, k = ci*9 + kh*3
+// + kw.  The pairs are chosen so that the two elements of a step lie a FIXED distance apart in the LDS image — one column
+// (steps 0-8: kw 0|1 of every (ci,kh)), one row (9-11: kw=2 of kh 0|1), one plane (12: (ci 0|1, kh 2, kw 2)); step 13 holds
+// (2,2,2) alone — so a lane needs three base addresses (base + h*distance) and every step's offset is an immediate,
+// instead of fourteen per-lane offset registers.
+struct HeadStep { int k0, k1, dist; };   // k1 < 0: the h=1 lanes multiply by a zero weight; dist: 0 column, 1 row, 2 plane
+__host__ __device__ constexpr HeadStep head_step(int s) {
+    return s < 9   ? HeadStep{(s / 3) * 9 + (s % 3) * 3, (s / 3) * 9 + (s % 3) * 3 + 1, 0}
+         : s < 12  ? HeadStep{(s - 9) * 9 + 2, (s - 9) * 9 + 5, 1}
+         : s == 12 ? HeadStep{8, 17, 2}
+                   : HeadStep{26, -1, 0};
+}
+// Host: (step, lane half) that multiplies element k.
+inline void head_step_of(int k, int& s, int& h) {
+    for (s = 0; s < 14; ++s) {
+        if (head_step(s).k0 == k) { h = 0; return; }
+        if (head_step(s).k1 == k) { h = 1; return; }
+    }
+    s = h = -1;
+}
+
 struct HeadArgs {
     const void* in;     // fp32 NCHW [N,3,H,W], or (IN_U8) uint8 NHWC [N,H,W,3]
     const float* w;     // packed [2 ns][14 steps][64 lanes]
@@ -521,13 +542,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #pragma unroll 1
     for (int m = 0; m < 2; ++m) {   // not unrolled: hipcc would interleave the two rows and double the live accumulators
         f32x16 acc[2];   // first written by the zero-C MFMAs of step 0
+        const int base_col = pbase + m * LW + h, base_row = pbase + m * LW + h * LW, base_plane = pbase + m * LW + h * PLANE;
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
-            // k = 2s+h flattens (ci, kh, kw) in the reference weight order [co][ci][kh][kw]; k = 27 is padding
-            const int k0 = 2 * s, k1 = (2 * s + 1 < 27) ? 2 * s + 1 : 0;
-            const int o0 = (k0 / 9) * PLANE + ((k0 % 9) / 3) * LW + (k0 % 3);
-            const int o1 = (k1 / 9) * PLANE + ((k1 % 9) / 3) * LW + (k1 % 3);
-            const float av = lds[pbase + m * LW + (h ? o1 : o0)];
+            const HeadStep hs = head_step(s);   // folds to constants after unrolling
+            const int o0 = (hs.k0 / 9) * PLANE + ((hs.k0 % 9) / 3) * LW + (hs.k0 % 3);   // immediate
+            const float av = lds[(hs.dist == 0 ? base_col : hs.dist == 1 ? base_row : base_plane) + o0];
 #pragma unroll
             for (int ns = 0; ns < 2; ++ns) {
                 if ((ABLATE & 2) && s > 0) { acc[ns][s] += av * bw[ns][s]; continue; }
