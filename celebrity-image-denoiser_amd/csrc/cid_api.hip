@@ -64,7 +64,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u2_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], zeros_off, tab_off[4], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u2_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[4], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -83,7 +83,6 @@ struct BlobLayout {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
             raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
-        zeros_off = o; o += 1024;   // 4 KiB of zeros (kept for ABI stability of the blob; the DMA zeros come from the range check)
         tab_off[0] = o; o = align_up(o + wino_slot_table(32, 2, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
         tab_off[1] = o; o = align_up(o + wino_slot_table(16, 4, nullptr), 64);
         tab_off[2] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // k_wino64_conv: half as many tile rows per workgroup

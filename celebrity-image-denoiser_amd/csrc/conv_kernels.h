@@ -84,19 +84,6 @@ __device__ __forceinline__ void decode_tile(int mt, int tiles_x, int tiles_y, un
     n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (unsigned)tiles_x);
 }
 
-// The workgroups of one launch all take the same time, so the WPC that share a CU would load, compute and store in
-// phase for the whole launch and nothing would overlap (a memory-bound kernel then runs at the SUM of its phases).
-// First-generation workgroups wait slot/WPC of one workgroup duration (`units` x ~3.4 us), by the wave slot they
-// landed in (HW_ID.WAVE_ID); later generations inherit the offsets.
-__device__ __forceinline__ void dephase_workgroups(int wpc, int units = 1) {
-    if (blockIdx.x < (unsigned)(wpc * 256)) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const int slot = (int)(hwid & 15u) % wpc;
-        for (int sl = 0; sl < slot * units; ++sl) __builtin_amdgcn_s_sleep(127);
-    }
-}
-
 // ---- wide store tail -------------------------------------------------------------------------
 // An MFMA accumulator tile holds, per lane, ONE output channel and 16 pixels, so storing it
 // directly costs one 4-byte global store per register (two 128-byte segments per instruction).

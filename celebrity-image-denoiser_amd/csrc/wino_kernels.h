@@ -17,7 +17,8 @@
 //     (one row a, 8 input channels: 4 positions b x 4 k-steps);
 //   * K is walked in 16-channel chunks through a double-buffered raw halo tile in LDS
 //     (pixel = 4 data slots + 1 pad slot of 16 B); the next chunk is written by LDS-DMA
-//     (global_load_lds_dwordx4: no VGPRs, no ds_write; out-of-image and pad slots read a zero page)
+//     (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write; out-of-image and pad slots carry an out-of-range offset and the
+//     buffer range check writes zeros)
 //     under the current chunk's MFMAs, ONE barrier per chunk;
 //   * B fragments (U, pre-packed per lane) stream L2 -> registers two units ahead;
 //   * epilogue: the halves exchange their partial output transforms through LDS, then half h writes
@@ -98,7 +99,7 @@ __device__ __forceinline__ void wino_item(const WinoArgs& a, f32x4* lds, int ite
     constexpr int NCHUNK = CIN / WK;
     constexpr int NB = COUT / WN;
     static_assert(CIN % WK == 0 && COUT % WN == 0 && (TC == 16 || TC == 32), "layer dims");
-    static_assert(RW <= 8 && CIN * 4 <= 4096, "DMA rounds per wave / zero page size");
+    static_assert(RW <= 8, "DMA rounds per wave");
 
     constexpr int EXCH = 4 * 16 * 64;            // epilogue exchange area: 4 waves x 16 registers x 64 lanes (f32x4)
     static_assert(2 * BUF <= 4096 && EXCH <= 4096 && 4 * 64 * WS32 * sizeof(float) <= 4096 * 16, "LDS budget (64 KiB)");
