@@ -99,6 +99,8 @@ def main():
                     help="f32 = the reference's arithmetic (the headline metric); f16 = BASELINE configs[4] (half storage, "
                          "fp16 MFMA with fp32 accumulators) — a different numerical contract, reported for that config only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the host-pipeline and single-image-latency legs (profiling runs: only the timed batches launch kernels)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -230,6 +232,12 @@ def main():
                                           "fp16 storage: max|delta|<=5e-4 at default weight scale (tests/test_gpu_parity.py)"}
         except Exception as e:  # pragma: no cover
             res["parity"] = {"error": str(e)[:200]}
+        if args.no_extras:
+            print(json.dumps(res))
+            if use_dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         # host-buffer round trips (reported, never `value`): (1) the serial H2D -> forward -> D2H of fp32 tensors the
         # reference's callers do; (2) the same through HostPipeline (copies overlapped on separate streams);
         # (3) uint8 images in and out through HostPipeline (4x less PCIe traffic)
