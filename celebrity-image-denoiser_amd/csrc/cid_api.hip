@@ -35,7 +35,7 @@ const char* kKernelNames[NL] = {
 const char* kHalfKernelNames[NL] = {
     "k_conv_head", "k_gemm_conv_h<64, 64, 1>", "k_gemm_conv_h<64, 128, 0>", "k_gemm_conv_h<128, 128, 1>",
     "k_gemm_conv_h<128, 256, 0>", "k_gemm_conv_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_gemm_conv_h<256, 128, 0>",
-    "k_gemm_conv_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_gemm_conv_h<128, 64, 0>", "k_conv_tail",
+    "k_gemm_conv_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_gemm_conv_h<128, 64, 0>", "k_conv_tail_h",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -78,6 +78,7 @@ struct BlobLayout {
         for (int l = 0; l < NL; ++l) {   // fp16-storage path: half weights of the GEMM layers (2 per float slot)
             h_off[l] = o;
             if (kLayers[l].kind == CONV || kLayers[l].kind == CONVT) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
+            if (kLayers[l].kind == TAIL) o = align_up(o + 4 * 64 * 8 / 2, 64);   // k_conv_tail_h: [4 k-steps][64 lanes][8] halfs
         }
         for (int l = 0; l < NL; ++l) {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
@@ -333,9 +334,9 @@ hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8, bool
     return hipGetLastError();
 }
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8, bool f16) {
-    if (u8 && f16) hipLaunchKernelGGL((k_conv_tail<true, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    if (u8 && f16) hipLaunchKernelGGL((k_conv_tail_h<true>), dim3(grid), dim3(THREADS), 0, s, a);
     else if (u8) hipLaunchKernelGGL((k_conv_tail<true, false>), dim3(grid), dim3(THREADS), 0, s, a);
-    else if (f16) hipLaunchKernelGGL((k_conv_tail<false, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (f16) hipLaunchKernelGGL((k_conv_tail_h<false>), dim3(grid), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_conv_tail<false, false>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
@@ -425,7 +426,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     STEP((launch_layer<128, 64, 0>(h, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
     {   // upconv1[2] + tanh, NHWC t4 -> NCHW out                                         app.py:77,103
         TailArgs a;
-        a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
+        a.in = B[T4]; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[11] : kBlob.w_off[11]); a.bias = blob + kBlob.b_off[11]; a.out = out;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
@@ -491,6 +492,13 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
         std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
         if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l], h->staging.data() + kBlob.u2_off[l]);
+        if (L.kind == TAIL) {   // half copy for k_conv_tail_h: [k-step s][lane = 32*h + col][e], ci = 16*s + 8*h + e, col = 3*tap + co
+            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                const int col = (kh * 3 + kw) * 3 + co, s = ci >> 4, hh = (ci >> 3) & 1, e = ci & 7;
+                hd[((size_t)s * 64 + hh * 32 + col) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
+            });
+        }
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });

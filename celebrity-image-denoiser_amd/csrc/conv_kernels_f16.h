@@ -204,4 +204,127 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail of the fp16-storage path: upconv1[2] + tanh (app.py:77,101,103) on a half NHWC input.  Same algorithm as
+// k_conv_tail (z = x . W for every halo pixel as a [352 x 64] x [64 x 32] product, then the nine shifted sums), but the
+// product runs on v_mfma_f32_32x32x16_f16 straight from the half tile: 4 MFMAs per 32 pixels instead of 32, no
+// half -> float conversion on the way into LDS, and all 64 channels of the tile fit the LDS that held one 32-channel fp32
+// chunk, so there is one load phase per tile.  Weights: half, [4 k-steps][lane = 32*h + col][8]  (cid_api.hip, TAIL).
+// The fp32 tail fed from half spent 0.63 ms at B=512 (twice the images per byte: its fp32 product alone is 0.3 ms).
+template <bool OUT_U8>
+__global__ void __launch_bounds__(THREADS, 2) k_conv_tail_h(const TailArgs a) {
+    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;   // 340 halo pixels
+    constexpr int MT = (LPIX + 31) / 32, LP = MT * 32;                // 11 M tiles, 352 rows
+    constexpr int NSLOT = LPIX * 8, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 16-byte pieces: 8 per pixel (64 halfs)
+    constexpr int ZS = 33;
+    __shared__ f32x4 lds[LP * PSLOTS];
+    static_assert(LP * ZS * sizeof(float) <= sizeof(lds), "z must fit where x was");
+    int grp, nb;
+    if (!decode_block(a.groups_total, a.groups_per_xcd, 1, grp, nb)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+
+    f16x8 wb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wb[s] = reinterpret_cast<const f16x8*>(a.w)[s * 64 + lane];
+    float bias_v[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bias_v[co] = a.bias[co];
+
+    const size_t img_elems = (size_t)a.H * a.W * 64;
+    int n, y0, x0;
+    __amdgpu_buffer_rsrc_t rsrc_in;
+    unsigned goff[NLOAD];
+    f32x4 stage[NLOAD];
+    auto request_tile = [&](int tile, int& tn, int& ty0, int& tx0) {
+        int ty, tx;
+        decode_tile(tile, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, tn, ty, tx);
+        ty0 = ty * TILE_H; tx0 = tx * TILE_W;
+        rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const _Float16*>(a.in) + (size_t)tn * img_elems), (short)0,
+                                                    (int)(img_elems * 2), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            const int p = s >> 3, c = s & 7;
+            const int hy = p / LW, hx = p - hy * LW;
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+            const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            goff[it] = ok ? (unsigned)(((gy * a.W + gx) * 64 + c * 8) * 2) : 0x7ffffff0u;
+        }
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], 0, 0));
+    };
+
+    const int tile0 = grp * a.tiles_per_wg;
+    const int ntile = min(a.tiles_per_wg, a.tiles_total - tile0);   // >= 1, workgroup-uniform
+    request_tile(tile0, n, y0, x0);
+    for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) {
+            const int s = it * THREADS + tid;
+            if (s < NSLOT) lds[lds_slot(s >> 3, s & 7)] = stage[it];
+        }
+        int nn = n, ny0 = y0, nx0 = x0;
+        if (t + 1 < ntile) request_tile(tile0 + t + 1, nn, ny0, nx0);   // in flight under the product and the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        f32x16 acc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int mtile = wave + 4 * q;          // wave-uniform
+            if (mtile < MT) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    // rows 340..351 of the last tile read never-written LDS: they only reach z rows nobody gathers
+                    const f16x8 av = __builtin_bit_cast(f16x8, lds[lds_slot(mtile * 32 + i, 2 * s + h)]);
+                    if (s == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wb[s], zero, 0, 0, 0);
+                    } else {
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wb[s], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // every wave is done reading x: the LDS becomes z[352][33]
+        float* zl = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int mtile = wave + 4 * q;
+            if (mtile < MT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zl[(mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ZS + i] = acc[q][r];
+            }
+        }
+        __syncthreads();
+        const int row = tid >> 5, col = tid & 31;
+        const int pb = row * LW + col;
+        float o[3] = {bias_v[0], bias_v[1], bias_v[2]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* zp = zl + (pb + (tap / 3) * LW + (tap % 3)) * ZS + tap * 3;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) o[co] += zp[co];
+        }
+        const int y = y0 + row, x = x0 + col;
+        if (y < a.H && x < a.W) {
+            if (OUT_U8) {
+                unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * 3;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
+                    op[co] = (unsigned char)(v * 255.0f);
+                }
+            } else {
+                const size_t plane = (size_t)a.H * a.W;
+                float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+                op[0] = tanhf(o[0]);
+                op[plane] = tanhf(o[1]);
+                op[2 * plane] = tanhf(o[2]);
+            }
+        }
+        __syncthreads();   // everyone is done gathering z before the next tile's pieces overwrite it
+        n = nn; y0 = ny0; x0 = nx0;
+    }
+}
+
 }  // namespace cid
