@@ -435,3 +435,24 @@ def test_graphed_forward_matches_eager(models):
         assert torch.equal(fast8(t), m.forward_u8(t))
     with pytest.raises(RuntimeError):
         fast(torch.zeros((2, 3, 24, 40), device="cuda:0"))
+
+
+def test_batch_past_2_31_elements_per_buffer(models):
+    """Maximum-size edge: 2080 images of 128x128 make the 64-channel buffers hold more than 2^31 elements (60 GiB arena).
+    Every 16-image group must equal the same 16 images run alone, bit for bit (64-bit base addresses, 32-bit per-image
+    offsets, tile decode by multiply-high)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * 2**30:
+        pytest.skip("needs ~70 GiB of free device memory")
+    m = models["hot"]
+    n = 2080
+    base, _, _ = synth.make_batch(16, 128, 128, first_index=7000)
+    x = torch.from_numpy(base).to("cuda:0").repeat(n // 16, 1, 1, 1).contiguous()
+    assert n * 128 * 128 * 64 > 2**31
+    y = m(x)
+    ref = m(x[:16].contiguous())
+    torch.cuda.synchronize()
+    assert all(torch.equal(y[k:k + 16], ref) for k in range(0, n, 16))
+    del x, y
+    m._ws = None            # give the arena back
+    torch.cuda.empty_cache()
