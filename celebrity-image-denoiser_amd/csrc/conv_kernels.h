@@ -210,6 +210,7 @@ __device__ __forceinline__ void wide_store_h_full(float* stg, int lane, ValFn va
 // ABLATE (timing experiments only, csrc/tools/layer_bench.hip; results are wrong when non-zero):
 //   bit 0: no halo prefetch/restage after chunk 0   bit 1: B fragments loaded once
 //   bit 2: A fragments read once per chunk          bit 3: no epilogue stores
+//   bit 4 (results stay correct, MODE 2): wave 0 writes s_memtime stamps and HW_ID to a.pool (layer_bench <N> trace, tools/trace_stats.py)
 template <int CIN, int COUT, int MODE, int ABLATE = 0, int WPS = 2>
 __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a) {
     constexpr int TAPS = (MODE == 2) ? 1 : 9;
@@ -238,6 +239,17 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    // ABLATE bit 4 (trace experiment, MODE 2 only): wave 0 records s_memtime at four points and its HW_ID into a.pool
+    unsigned long long* trace = (ABLATE & 16) ? reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8 : nullptr;
+    if ((ABLATE & 16) && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        trace[0] = __builtin_readcyclecounter();
+        trace[4] = hwid;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[5] = xcc;
+    }
 
     // output-channel block of this workgroup (MODE 2: nb also selects the (kh,kw) tap)
     constexpr int CB = COUT / NTILE;
@@ -354,9 +366,11 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
         }
     };
     static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
+    if ((ABLATE & 16) && tid == 0) trace[1] = __builtin_readcyclecounter();
     chunk(std::true_type{}, std::true_type{}, 0);
     for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
     chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
+    if ((ABLATE & 16) && tid == 0) trace[2] = __builtin_readcyclecounter();
 
     if (ABLATE & 8) {   // keep the accumulators alive without the store tail
         float sum = 0.f;
@@ -392,6 +406,11 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
             else
                 wide_store<32>(stg, lane, val, xo,
                                [&](int px) -> float* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+        }
+        if ((ABLATE & 16) && tid == 0) {
+            trace[3] = __builtin_readcyclecounter();                 // all stores issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            trace[6] = __builtin_readcyclecounter();                 // ... and written back
         }
     } else {
 #pragma unroll

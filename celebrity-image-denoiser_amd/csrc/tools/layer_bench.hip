@@ -140,6 +140,29 @@ int main(int argc, char** argv) {
         v.push_back(make<128, 64, 2, 8, 2>("T no-stores", N, 64, 64, inA, wA, bA, outA, nullptr));
         v.push_back(make<128, 64, 2, 15, 2>("T mfma-only", N, 64, 64, inA, wA, bA, outA, nullptr));
     }
+    if (argc > 2 && std::string(argv[2]) == "trace") {
+        // One launch of the transposed conv (up1 shape) with s_memtime stamps per workgroup: where does a workgroup's time go,
+        // and what happens on a CU between one workgroup's stores and the next one's first MFMA?
+        const int H = 64, W = 64;
+        const int tiles = N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+        const int nwg = 8 * ((tiles + 7) / 8) * 4;
+        unsigned long long* tr; CK(hipMalloc(&tr, (size_t)nwg * 8 * 8)); CK(hipMemset(tr, 0, (size_t)nwg * 8 * 8));
+        Variant t = make<128, 64, 2, 16, 2>("trace", N, H, W, inA, wA, bA, outA, reinterpret_cast<float*>(tr));
+        t.run(s); CK(hipStreamSynchronize(s));    // warm
+        CK(hipMemset(tr, 0, (size_t)nwg * 8 * 8));
+        t.run(s); CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)nwg * 8);
+        CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+        std::FILE* f = std::fopen("gpurun_out/convt_trace.csv", "w");
+        std::fprintf(f, "wg,t_start,t_main,t_main_end,t_stores_issued,t_stores_done,hw_id,xcc_id\n");
+        for (int i = 0; i < nwg; ++i)
+            if (h[(size_t)i * 8])
+                std::fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, h[(size_t)i * 8], h[(size_t)i * 8 + 1], h[(size_t)i * 8 + 2],
+                             h[(size_t)i * 8 + 3], h[(size_t)i * 8 + 6], h[(size_t)i * 8 + 4], h[(size_t)i * 8 + 5]);
+        std::fclose(f);
+        std::printf("trace written: %d workgroups\n", nwg);
+        return 0;
+    }
     std::vector<std::vector<float>> ms(v.size());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& x : v) x.run(s);   // warm-up
