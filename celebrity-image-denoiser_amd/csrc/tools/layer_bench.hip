@@ -161,6 +161,26 @@ int main(int argc, char** argv) {
                              h[(size_t)i * 8 + 3], h[(size_t)i * 8 + 6], h[(size_t)i * 8 + 4], h[(size_t)i * 8 + 5]);
         std::fclose(f);
         std::printf("trace written: %d workgroups\n", nwg);
+        {   // the same for the dominant Winograd launch (upconv1.0 shape)
+            const int nwg2 = 8 * ((N * 2 * 64 + 7) / 8);
+            unsigned long long* tr2; CK(hipMalloc(&tr2, (size_t)nwg2 * 16 * 8)); CK(hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8));
+            Variant w = makew64<128, 64, false, 32, 256>("trace64", N, 128, 128, inA, uA, bA, outA, reinterpret_cast<float*>(tr2));
+            w.run(s); CK(hipStreamSynchronize(s));
+            CK(hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8));
+            w.run(s); CK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h2((size_t)nwg2 * 16);
+            CK(hipMemcpy(h2.data(), tr2, h2.size() * 8, hipMemcpyDeviceToHost));
+            std::FILE* f2 = std::fopen("gpurun_out/wino64_trace.csv", "w");
+            std::fprintf(f2, "wg,t_start,t_main,t_main_end,t_stores_issued,t_stores_done,hw_id,xcc_id,t_table,t_dma_issued,t_dma_landed,t_dma_all,t_ep_b1,t_ep_b2,t_ep_b3,t_dma0,t_dma1\n");
+            for (int i = 0; i < nwg2; ++i) {
+                const unsigned long long* r = h2.data() + (size_t)i * 16;
+                if (r[0])
+                    std::fprintf(f2, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, r[0], r[1], r[2], r[3], r[6], r[4], r[5],
+                                 r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15], r[7]);
+            }
+            std::fclose(f2);
+            std::printf("wino64 trace written: %d workgroups\n", nwg2);
+        }
         return 0;
     }
     std::vector<std::vector<float>> ms(v.size());

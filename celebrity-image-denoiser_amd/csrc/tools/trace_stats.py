@@ -40,3 +40,9 @@ for key, v in cu.items():
     conc.append([a / span for a in acc])
 print("start-after-previous-end gap: median", st.median(gaps), " p90", q(gaps, .9))
 print("fraction of a CU's time with 0 / 1 / 2 workgroups in the main loop:", [round(st.mean(c[i] for c in conc), 3) for i in range(3)])
+if "t_table" in rows[0]:
+    seq = ["t_start", "t_table", "t_dma1", "t_dma0", "t_dma_issued", "t_dma_landed", "t_dma_all", "t_main", "t_main_end", "t_ep_b1", "t_ep_b2", "t_ep_b3", "t_stores_issued", "t_stores_done"]
+    print("phase-by-phase medians (ticks):")
+    for a_, b_ in zip(seq, seq[1:]):
+        d = [r[b_] - r[a_] for r in rows if r[a_] and r[b_]]
+        print(f"  {a_:16s} -> {b_:16s} median {st.median(d):8.0f}  p90 {q(d, .9):8.0f}")

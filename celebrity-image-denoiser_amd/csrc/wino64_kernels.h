@@ -27,7 +27,7 @@ constexpr int WN2 = 64;       // output channels per workgroup
 
 // ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue,
 // 2 B quads loaded once, 4 A operand built once, 8 no epilogue, 16 epilogue without the global stores, 32 no per-chunk
-// barrier, 64 no prologue DMA, 128 no de-phasing of the two workgroups of a CU.
+// barrier, 64 no prologue DMA, 128 no de-phasing of the two workgroups of a CU, 256 s_memtime trace into a.pool (results stay correct).
 template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     constexpr int TRW = 32 / TC;                 // tile rows per workgroup
@@ -58,6 +58,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     const int i = lane & 31, h = lane >> 5;
     const int tr = i / TC, tc = i - tr * TC;
 
+    // ABLATE bit 8 (trace experiment, results stay correct, non-POOL layers): thread 0 writes s_memtime stamps + HW_ID to a.pool
+    unsigned long long* trace = (ABLATE & 256) ? reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 16 : nullptr;
+    if ((ABLATE & 256) && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[0] = __builtin_readcyclecounter(); trace[4] = hwid; trace[5] = xcc;
+    }
     const float bias_v = a.bias[nb * WN2 + (wave >> 1) * 32 + i];   // epilogue role of wave w: column block w>>1, tiles 16*(w&1)..+16
 
     if (blockIdx.x < 2 * 256) {   // de-phase the two workgroups of a CU once (see k_wino_conv)
@@ -99,6 +107,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             voff[m] = (off & keep) | (0x7ffffff0u & ~keep);
         }
     }
+    if ((ABLATE & 256) && tid == 0) trace[8] = __builtin_readcyclecounter() + (voff[0] & 0u);   // slot table arrived, offsets formed
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_chunk = [&](int buf, int ck) {
         const int soff = ck * (WK * 4);
@@ -122,15 +131,21 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     };
 
     // ---- prologue: chunks 0 and 1 -> both LDS buffers; B of unit 0 ----
-    if (!(ABLATE & 64)) {   // bit 6 (experiment): no prologue DMA
-        dma_chunk(0, 0);
-        dma_chunk(1, 1);
-    }
+    // Only what the first unit needs is requested before the first MFMA: the B quads of unit 0 (L2 hits) and chunk 0.
+    // Under load the vector-memory instructions of a cold prologue take ~1k cycles EACH to issue (s_memtime trace,
+    // tools/trace_stats.py): requesting chunk 1 here as well kept the workgroup out of its main loop 4k cycles longer;
+    // it is requested at the start of chunk 0's unit 0 instead and has that unit to land.
     f32x4 bq[2][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) bq[q >> 2][q & 3] = b_load(0, q);
+    if ((ABLATE & 256) && tid == 0) trace[7] = __builtin_readcyclecounter();    // B requested
+    if (!(ABLATE & 64)) dma_chunk(0, 0);   // bit 6 (experiment): no prologue DMA
+    if ((ABLATE & 256) && tid == 0) trace[15] = __builtin_readcyclecounter();   // chunk 0 requested
+    if ((ABLATE & 256) && tid == 0) trace[9] = __builtin_readcyclecounter();    // DMA and B loads issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to hipcc's own wait counting
+    if ((ABLATE & 256) && tid == 0) trace[10] = __builtin_readcyclecounter();   // ... and landed (this wave)
     __syncthreads();
+    if ((ABLATE & 256) && tid == 0) trace[11] = __builtin_readcyclecounter();   // ... in every wave
 
     auto read_cols = [&](f32x4 (&xq)[2], f32x4 (&yq)[2], int bufbase, int g2, int c0) {
 #pragma unroll
@@ -176,6 +191,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             const int nbuf = (k == 0) ? cur : nxt, ng2 = 1 - k;
             f32x4 xq[2], yq[2], t[4];
             // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
+            if (FIRST && k == 0 && !(ABLATE & 65)) dma_chunk(1, 1);          // chunk 1: see the prologue
             if (DMA && k == 1 && !(ABLATE & 1)) dma_chunk(PAR, ck + 2);
             const bool build = have_next_unit && !(ABLATE & 4);
             if (build) read_cols(xq, yq, nbuf, ng2, 0);
@@ -226,6 +242,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     };
     using T = std::true_type;
     using F = std::false_type;
+    if ((ABLATE & 256) && tid == 0) trace[1] = __builtin_readcyclecounter();
     chunk(T{}, T{}, T{}, F{}, 0);
     chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
     for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
@@ -235,6 +252,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     }
     chunk(F{}, T{}, F{}, F{}, NCHUNK - 2);
     chunk(F{}, F{}, F{}, T{}, NCHUNK - 1);
+    if ((ABLATE & 256) && tid == 0) trace[2] = __builtin_readcyclecounter();
 
     // ---- output transform ----
     // Four code versions selected by a wave-uniform switch, so that "is this my own row / my own block" is a
@@ -255,6 +273,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
         constexpr int W = decltype(wave_tag)::value;
         constexpr int NT_W = W >> 1, RH = W & 1;                // epilogue role: column block, tile half
         __syncthreads();                                        // raw tiles are dead: LDS becomes the exchange area
+        if ((ABLATE & 256) && tid == 0) trace[12] = __builtin_readcyclecounter();
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         // exchange block (src row a, dst wave w): 8 registers x 64 lanes of f32x2 = 4 KiB at ((a*4 + w) * 512) f32x2
         f32x2* ex = reinterpret_cast<f32x2*>(lds);
@@ -271,6 +290,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
                 else ex[(W * 4 + w) * 512 + (r & 7) * 64 + lane] = m;
             }
         __syncthreads();
+        if ((ABLATE & 256) && tid == 0) trace[13] = __builtin_readcyclecounter();
         float y[2][2][8];   // [output row a'][column b'][register]
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -284,6 +304,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             }
         }
         __syncthreads();                                        // exchange area is dead: reuse as store staging
+        if ((ABLATE & 256) && tid == 0) trace[14] = __builtin_readcyclecounter();
         float* stg = reinterpret_cast<float*>(lds) + W * (64 * WS32);
         // register rr of this wave is tile  T = 16*RH + (rr&3) + 8*(rr>>2) + 4*h  of the workgroup's 32
         auto tl_of = [&](int rr) { return (rr & 3) + 8 * (rr >> 2) + 4 * h; };
@@ -344,6 +365,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
         case 1: epilogue(std::integral_constant<int, 1>{}); break;
         case 2: epilogue(std::integral_constant<int, 2>{}); break;
         default: epilogue(std::integral_constant<int, 3>{}); break;
+    }
+    if ((ABLATE & 256) && tid == 0) {
+        trace[3] = __builtin_readcyclecounter();                 // this wave's stores are issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace[6] = __builtin_readcyclecounter();                 // ... and written back
     }
 }
 
