@@ -180,6 +180,26 @@ int main(int argc, char** argv) {
             }
             std::fclose(f2);
             std::printf("wino64 trace written: %d workgroups\n", nwg2);
+            // main-loop duration (stamps 1 -> 2) with one component removed at a time
+            auto main_median = [&](Variant v2, const char* nm) {
+                hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
+                v2.run(s); hipStreamSynchronize(s);
+                hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
+                v2.run(s); hipStreamSynchronize(s);
+                hipMemcpy(h2.data(), tr2, h2.size() * 8, hipMemcpyDeviceToHost);
+                std::vector<unsigned long long> d, tot;
+                for (int i = 0; i < nwg2; ++i) { const unsigned long long* r = h2.data() + (size_t)i * 16; if (r[0] && r[2] > r[1]) { d.push_back(r[2] - r[1]); tot.push_back((r[3] ? r[3] : r[2]) - r[0]); } }
+                std::sort(d.begin(), d.end()); std::sort(tot.begin(), tot.end());
+                std::printf("%-34s main loop median %6llu cycles, workgroup (start -> stores issued) %6llu\n", nm, d[d.size() / 2], tot[tot.size() / 2]);
+            };
+            float* trf = reinterpret_cast<float*>(tr2);
+            main_median(makew64<128, 64, false, 32, 256>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 base");
+            main_median(makew64<128, 64, false, 32, 256 + 1>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 no DMA after prologue");
+            main_median(makew64<128, 64, false, 32, 256 + 2>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 B loaded once");
+            main_median(makew64<128, 64, false, 32, 256 + 4>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 A built once");
+            main_median(makew64<128, 64, false, 32, 256 + 32>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 no per-chunk barrier");
+            main_median(makew64<128, 64, false, 32, 256 + 7>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 MFMA + barriers only");
+            main_median(makew64<128, 64, false, 32, 256 + 39>("", N, 128, 128, inA, uA, bA, outA, trf), "wino64 MFMA only");
         }
         return 0;
     }
