@@ -182,11 +182,11 @@ int main(int argc, char** argv) {
             std::printf("wino64 trace written: %d workgroups\n", nwg2);
             // main-loop duration (stamps 1 -> 2) with one component removed at a time
             auto main_median = [&](Variant v2, const char* nm) {
-                hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
-                v2.run(s); hipStreamSynchronize(s);
-                hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
-                v2.run(s); hipStreamSynchronize(s);
-                hipMemcpy(h2.data(), tr2, h2.size() * 8, hipMemcpyDeviceToHost);
+                (void)hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
+                v2.run(s); (void)hipStreamSynchronize(s);
+                (void)hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8);
+                v2.run(s); (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h2.data(), tr2, h2.size() * 8, hipMemcpyDeviceToHost);
                 std::vector<unsigned long long> d, tot;
                 for (int i = 0; i < nwg2; ++i) { const unsigned long long* r = h2.data() + (size_t)i * 16; if (r[0] && r[2] > r[1]) { d.push_back(r[2] - r[1]); tot.push_back((r[3] ? r[3] : r[2]) - r[0]); } }
                 std::sort(d.begin(), d.end()); std::sort(tot.begin(), tot.end());
