@@ -44,6 +44,7 @@ SYMBOLS = {
     "cid_launch_kernel": (_c.c_char_p, [_c.c_void_p, _c.c_int]),
     "cid_set_conv_algo": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_conv_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "cid_debug_poison_lds": (_c.c_int, [_c.c_void_p]),
     "cid_set_compute_dtype": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_compute_dtype": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_launch_work": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),

@@ -678,6 +678,21 @@ int cid_get_compute_dtype(cid_handle_t h, int* dtype) {
     *dtype = h->dtype;
     return CID_OK;
 }
+// Testing aid: leave NaN in every byte of every CU's LDS.  LDS is not cleared between kernels, so whatever the forward's
+// kernels read from LDS without having written it is NaN afterwards (a zero weight does not hide that: 0 x NaN = NaN).
+__global__ void __launch_bounds__(256) k_poison_lds() {
+    __shared__ float lds[8192];   // 32 KiB: five of these blocks fit a CU and together cover its 160 KiB
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = __builtin_nanf("");
+    __syncthreads();
+    for (int sl = 0; sl < 8; ++sl) __builtin_amdgcn_s_sleep(127);   // stay resident while the CU's other slots fill up
+    const float v = lds[threadIdx.x];
+    asm volatile("" ::"v"(v));
+}
+int cid_debug_poison_lds(void* stream) {
+    hipLaunchKernelGGL(k_poison_lds, dim3(256 * 5 * 4), dim3(256), 0, static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? CID_OK : CID_ERR_HIP;
+}
+
 int cid_get_conv_algo(cid_handle_t h, int* algo) {
     if (!h || !algo) return CID_ERR_INVALID;
     *algo = h->algo;

@@ -450,15 +450,17 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
 // to 28 = 14 MFMA k-steps; memory-bound on its 64-channel NHWC output.
 // K order of the head's 14 MFMA steps.  Step s multiplies element k0(s) on lanes h=0 and k1(s) on lanes h=1, k = ci*9 + kh*3
 // + kw.  The pairs are chosen so that the two elements of a step lie a FIXED distance apart in the LDS image — one column
-// (steps 0-8: kw 0|1 of every (ci,kh)), one row (9-11: kw=2 of kh 0|1), one plane (12: (ci 0|1, kh 2, kw 2)); step 13 holds
-// (2,2,2) alone — so a lane needs three base addresses (base + h*distance) and every step's offset is an immediate,
-// instead of fourteen per-lane offset registers.
-struct HeadStep { int k0, k1, dist; };   // k1 < 0: the h=1 lanes multiply by a zero weight; dist: 0 column, 1 row, 2 plane
+// (steps 0-8: kw 0|1 of every (ci,kh)), one row (9-11: kw=2 of kh 0|1), one plane (12: (ci 0|1, kh 2, kw 2)) — so a lane needs
+// three base addresses (base + h*distance) and every step's offset is an immediate, instead of fourteen per-lane offset
+// registers.  Step 13 holds (2,2,2) alone, on the h=1 lanes one row below the step's address (2,1,2); the h=0 lanes read
+// (2,1,2) itself against a ZERO weight.  Both are elements the kernel has written: a zero weight does not make an
+// unwritten LDS word harmless (0 x NaN = NaN, and ReLU then turns the NaN into a wrong 0).
+struct HeadStep { int addr, k0, k1, dist; };   // addr: element whose offset is the immediate; k0/k1: weights of the h=0/1 lanes (-1 = 0)
 __host__ __device__ constexpr HeadStep head_step(int s) {
-    return s < 9   ? HeadStep{(s / 3) * 9 + (s % 3) * 3, (s / 3) * 9 + (s % 3) * 3 + 1, 0}
-         : s < 12  ? HeadStep{(s - 9) * 9 + 2, (s - 9) * 9 + 5, 1}
-         : s == 12 ? HeadStep{8, 17, 2}
-                   : HeadStep{26, -1, 0};
+    return s < 9   ? HeadStep{(s / 3) * 9 + (s % 3) * 3, (s / 3) * 9 + (s % 3) * 3, (s / 3) * 9 + (s % 3) * 3 + 1, 0}
+         : s < 12  ? HeadStep{(s - 9) * 9 + 2, (s - 9) * 9 + 2, (s - 9) * 9 + 5, 1}
+         : s == 12 ? HeadStep{8, 8, 17, 2}
+                   : HeadStep{23, -1, 26, 1};
 }
 // Host: (step, lane half) that multiplies element k.
 inline void head_step_of(int k, int& s, int& h) {
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
             const HeadStep hs = head_step(s);   // folds to constants after unrolling
-            const int o0 = (hs.k0 / 9) * PLANE + ((hs.k0 % 9) / 3) * LW + (hs.k0 % 3);   // immediate
+            const int o0 = (hs.addr / 9) * PLANE + ((hs.addr % 9) / 3) * LW + (hs.addr % 3);   // immediate
             const float av = lds[(hs.dist == 0 ? base_col : hs.dist == 1 ? base_row : base_plane) + o0];
 #pragma unroll
             for (int ns = 0; ns < 2; ++ns) {

@@ -1,0 +1,19 @@
+"""Ad-hoc: many large random batches through both Winograd kernels; any synchronisation race in one of them (LDS-DMA waits,
+barriers, LDS reuse in the epilogues) would show up as a bit difference between the two, or between two runs of one."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/../../..")
+import celebrity_image_denoiser_amd as cid
+from celebrity_image_denoiser_amd import synth
+m = cid.load(synth.make_state_dict("hot"), device="cuda:0", strict=True)
+g = torch.Generator(device="cuda:0"); g.manual_seed(1234)
+bad = 0
+for it in range(40):
+    n, hw = (192, 128) if it % 2 == 0 else (96, int(torch.randint(33, 200, (1,)).item()))
+    x = (torch.rand((n, 3, hw, hw + (it % 5) * 3), device="cuda:0", generator=g) * 2 - 1).contiguous()
+    m.conv_algo = "winograd64"; a = m(x).clone(); b = m(x).clone()
+    m.conv_algo = "winograd"; c = m(x).clone()
+    torch.cuda.synchronize()
+    if not (torch.equal(a, b) and torch.equal(a, c)):
+        bad += 1; print("MISMATCH at iteration", it, tuple(x.shape), float((a - b).abs().max()), float((a - c).abs().max()))
+print("iterations with a mismatch:", bad)
+sys.exit(1 if bad else 0)

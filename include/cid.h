@@ -175,6 +175,12 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
 
+/*
+ * Testing aid (no reference counterpart): fills the LDS of every CU with NaN on `stream`.  LDS is not cleared between
+ * kernels, so a forward enqueued after it exposes any kernel that reads LDS words it has not written.
+ */
+int cid_debug_poison_lds(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

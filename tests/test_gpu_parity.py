@@ -456,3 +456,29 @@ def test_batch_past_2_31_elements_per_buffer(models):
     del x, y
     m._ws = None            # give the arena back
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_no_kernel_reads_unwritten_lds_or_arena(models, weight_sets, dtype):
+    """Every byte of the CUs' LDS and of the activation arena is NaN before the forward (cid_debug_poison_lds; LDS is not
+    cleared between kernels).  A kernel that reads an LDS word or an arena element nobody has written would put NaN (or,
+    after a ReLU, a wrong 0) into the result: the output must be the bits of an unpoisoned run.  Multi-tile, ragged and
+    minimum shapes, uint8 and fp32 callers' formats."""
+    from celebrity_image_denoiser_amd import _lib
+
+    m = models["hot"]
+    m.compute_dtype = dtype
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        for (n, h, w) in ((3, 128, 128), (2, 40, 72), (1, 21, 30), (2, 4, 4)):
+            x, _, noisy = synth.make_batch(n, h, w, first_index=5000)
+            xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
+            want, want8 = m(xd).clone(), m.forward_u8(ud).clone()
+            for fn, ref in ((lambda: m(xd), want), (lambda: m.forward_u8(ud), want8)):
+                m._ws.view(torch.float32).fill_(float("nan"))
+                assert _lib.lib().cid_debug_poison_lds(stream) == 0
+                got = fn()
+                torch.cuda.synchronize()
+                assert torch.equal(got, ref), (dtype, n, h, w)
+    finally:
+        m.compute_dtype = "f32"
