@@ -40,6 +40,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     constexpr int NCHUNK = CIN / WK;
     constexpr int NB = COUT / WN2;
     constexpr int HWD = LWS / 2;
+    // Same-box A/B of the whole forward, layer by layer: spreading the DMA rounds over the MFMA groups gains 1-2.6 % on the layers
+    // with CIN <= 128 and loses ~1 % on the two with CIN = 256 (twice as many chunk seams per workgroup); chosen per layer.
+    constexpr bool DMA_SPREAD = CIN <= 128;
     static_assert(CIN % WK == 0 && COUT % WN2 == 0 && (TC == 16 || TC == 32), "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
     constexpr int LDS_SLOTS_K = 4096;            // 64 KiB: 2 raw buffers, later the 4x4 exchange blocks, later store staging
@@ -109,15 +112,16 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     }
     if ((ABLATE & 256) && tid == 0) trace[8] = __builtin_readcyclecounter() + (voff[0] & 0u);   // slot table arrived, offsets formed
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
-    auto dma_chunk = [&](int buf, int ck) {
-        const int soff = ck * (WK * 4);
-#pragma unroll
-        for (int m = 0; m < RW; ++m) {
-            if (wave + 4 * m < NROUND) {               // wave-uniform
-                const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
-            }
+    auto dma_round = [&](int buf, int ck, int m) {   // round m of this wave: 64 slots of chunk ck -> LDS buffer `buf`
+        if (wave + 4 * m < NROUND) {                   // wave-uniform
+            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
+            const int soff = ck * (WK * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
         }
+    };
+    auto dma_chunk = [&](int buf, int ck) {
+#pragma unroll
+        for (int m = 0; m < RW; ++m) dma_round(buf, ck, m);
     };
 
     f32x16 acc[2][4];   // [column block nt][position b]; first written by the zero-C MFMAs of chunk 0
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             f32x4 xq[2], yq[2], t[4];
             // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
             if (FIRST && k == 0 && !(ABLATE & 65)) dma_chunk(1, 1);          // chunk 1: see the prologue
-            if (DMA && k == 1 && !(ABLATE & 1)) dma_chunk(PAR, ck + 2);
+            if (!DMA_SPREAD && DMA && k == 1 && !(ABLATE & 1)) dma_chunk(PAR, ck + 2);
             const bool build = have_next_unit && !(ABLATE & 4);
             if (build) read_cols(xq, yq, nbuf, ng2, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -202,6 +206,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int nt = g >> 2, e = g & 3;
+                // DMA_SPREAD: one DMA round per MFMA group instead of RW in a row at the start of the unit — a vector-memory
+                // instruction takes 40-600 cycles to issue (tools/issue_bench) and a lone wave issues nothing else meanwhile.
+                // The counted wait at the next barrier still holds: after the last round (group RW-1 <= 7) come at least the
+                // 8 B refills of the next unit.
+                if (DMA_SPREAD && DMA && k == 1 && !(ABLATE & 1) && g < RW) dma_round(PAR, ck + 2, g);
                 if (build) {
                     if (g == 2) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
                     if (g == 4) {
