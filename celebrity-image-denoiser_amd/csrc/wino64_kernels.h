@@ -40,9 +40,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     constexpr int NCHUNK = CIN / WK;
     constexpr int NB = COUT / WN2;
     constexpr int HWD = LWS / 2;
-    // Same-box A/B of the whole forward, layer by layer: spreading the DMA rounds over the MFMA groups gains 1-2.6 % on the layers
-    // with CIN <= 128 and loses ~1 % on the two with CIN = 256 (twice as many chunk seams per workgroup); chosen per layer.
-    constexpr bool DMA_SPREAD = CIN <= 128;
+    // Same-box A/B of the whole forward, layer by layer: one DMA round per MFMA group gains 1-2.6 % over a burst on the layers with
+    // CIN <= 128 and loses ~1 % on the two with CIN = 256, where two rounds per group gain 1.2-1.5 %; chosen per layer.
+#ifdef CID_DMA_PER_GROUP
+    constexpr int DMA_PER_GROUP = CID_DMA_PER_GROUP;
+#else
+    constexpr int DMA_PER_GROUP = CIN <= 128 ? 1 : 2;
+#endif
     static_assert(CIN % WK == 0 && COUT % WN2 == 0 && (TC == 16 || TC == 32), "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
     constexpr int LDS_SLOTS_K = 4096;            // 64 KiB: 2 raw buffers, later the 4x4 exchange blocks, later store staging
@@ -196,7 +200,6 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             f32x4 xq[2], yq[2], t[4];
             // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
             if (FIRST && k == 0 && !(ABLATE & 65)) dma_chunk(1, 1);          // chunk 1: see the prologue
-            if (!DMA_SPREAD && DMA && k == 1 && !(ABLATE & 1)) dma_chunk(PAR, ck + 2);
             const bool build = have_next_unit && !(ABLATE & 4);
             if (build) read_cols(xq, yq, nbuf, ng2, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -206,11 +209,15 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int nt = g >> 2, e = g & 3;
-                // DMA_SPREAD: one DMA round per MFMA group instead of RW in a row at the start of the unit — a vector-memory
+                // DMA_PER_GROUP rounds per MFMA group instead of RW in a row at the start of the unit — a vector-memory
                 // instruction takes 40-600 cycles to issue (tools/issue_bench) and a lone wave issues nothing else meanwhile.
-                // The counted wait at the next barrier still holds: after the last round (group RW-1 <= 7) come at least the
-                // 8 B refills of the next unit.
-                if (DMA_SPREAD && DMA && k == 1 && !(ABLATE & 1) && g < RW) dma_round(PAR, ck + 2, g);
+                // The counted wait at the next barrier still holds: after the last round (group <= 7) come at least the 8 B
+                // refills of the next unit.
+                if (DMA && k == 1 && !(ABLATE & 1)) {
+#pragma unroll
+                    for (int j = 0; j < DMA_PER_GROUP; ++j)
+                        if (DMA_PER_GROUP * g + j < RW) dma_round(PAR, ck + 2, DMA_PER_GROUP * g + j);
+                }
                 if (build) {
                     if (g == 2) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
                     if (g == 4) {
