@@ -201,7 +201,12 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
             // this buffer's last reads (building unit 1) happened during unit 0, before the barrier below
             if (FIRST && k == 0 && !(ABLATE & 65)) dma_chunk(1, 1);          // chunk 1: see the prologue
             const bool build = have_next_unit && !(ABLATE & 4);
-            if (build) read_cols(xq, yq, nbuf, ng2, 0);
+            // the eight LDS reads of the next unit's A operand go out two per MFMA group (groups 0-3), not four at a time
+            auto read_col = [&](int slot, int c) {   // x and y of patch column c into pair slot `slot`
+                xq[slot] = lds[nbuf + xb + 2 * ng2 + col_off(c)];
+                yq[slot] = lds[nbuf + yb + 2 * ng2 + col_off(c)];
+            };
+            if (build) read_col(0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // 8 groups of four MFMAs, group g = (column block nt = g/4, k-step e = g%4): one column block's four k-steps
             // first, i.e. the same four accumulators in rotation for 16 MFMAs (measured 1.5 % faster than alternating
@@ -219,7 +224,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
                         if (DMA_PER_GROUP * g + j < RW) dma_round(PAR, ck + 2, DMA_PER_GROUP * g + j);
                 }
                 if (build) {
-                    if (g == 2) { make_t(t, xq, yq, 0); read_cols(xq, yq, nbuf, ng2, 2); }
+                    if (g == 1) read_col(1, 1);
+                    if (g == 2) { make_t(t, xq, yq, 0); read_col(0, 2); }
+                    if (g == 3) read_col(1, 3);
                     if (g == 4) {
                         make_t(t, xq, yq, 2);
 #pragma unroll
