@@ -42,6 +42,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     constexpr int HWD = LWS / 2;
     // Same-box A/B of the whole forward, layer by layer: one DMA round per MFMA group gains 1-2.6 % over a burst on the layers with
     // CIN <= 128 and loses ~1 % on the two with CIN = 256, where two rounds per group gain 1.2-1.5 %; chosen per layer.
+    // Side work of an MFMA group (DMA rounds, transform VALU, LDS reads, B refill) either in front of the group's four MFMAs or
+    // one piece after each of them.  Same-box A/B, layer by layer: the interleaved form gains 0.5-2 % on the layers with
+    // CIN >= 128 and loses 1.5-4 % on the two with CIN = 64.
+    constexpr bool INTERLEAVE = CIN >= 128;
 #ifdef CID_DMA_PER_GROUP
     constexpr int DMA_PER_GROUP = CID_DMA_PER_GROUP;
 #else
@@ -218,6 +222,47 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
                 // instruction takes 40-600 cycles to issue (tools/issue_bench) and a lone wave issues nothing else meanwhile.
                 // The counted wait at the next barrier still holds: after the last round (group <= 7) come at least the 8 B
                 // refills of the next unit.
+                if (INTERLEAVE) {
+                auto mfma = [&](int b) {
+                    if (FIRST && k == 0 && e == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], zero, 0, 0, 0);
+                    } else {
+                        acc[nt][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[b][e], bq[nt][e][b], acc[nt][b], 0, 0, 0);
+                    }
+                };
+                mfma(0);
+                if (DMA && k == 1 && !(ABLATE & 1)) {
+#pragma unroll
+                    for (int j = 0; j < DMA_PER_GROUP; ++j)
+                        if (DMA_PER_GROUP * g + j < RW) dma_round(PAR, ck + 2, DMA_PER_GROUP * g + j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(1);
+                if (build) {
+                    if (g == 2) make_t(t, xq, yq, 0);
+                    if (g == 4) {
+                        make_t(t, xq, yq, 2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[0][q] = t[0][q] - t[2][q]; vnxt[1][q] = t[1][q] + t[2][q]; }
+                    }
+                    if (g == 6) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { vnxt[2][q] = t[2][q] - t[1][q]; vnxt[3][q] = t[1][q] - t[3][q]; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(2);
+                if (build) {
+                    if (g == 1) read_col(1, 1);
+                    if (g == 2) read_col(0, 2);
+                    if (g == 3) read_col(1, 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(3);
+                if (have_next_unit && !(ABLATE & 2)) bq[nt][e] = b_load(ck * 2 + k + 1, nt * 4 + e);
+                __builtin_amdgcn_sched_barrier(0);
+                } else {
                 if (DMA && k == 1 && !(ABLATE & 1)) {
 #pragma unroll
                     for (int j = 0; j < DMA_PER_GROUP; ++j)
@@ -248,6 +293,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
                 }
                 if (have_next_unit && !(ABLATE & 2)) bq[nt][e] = b_load(ck * 2 + k + 1, nt * 4 + e);
                 __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (build) {
 #pragma unroll
