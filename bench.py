@@ -92,9 +92,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--weights", default="default", choices=["default", "hot"])
-    ap.add_argument("--algo", default="winograd64", choices=["winograd", "winograd64", "direct"],
+    ap.add_argument("--algo", default="winograd64", choices=["winograd64", "direct"],
                     help="algorithm of the eight 3x3 GEMM layers (all fp32): winograd64 = Winograd F(2x2,3x3), 64 output channels per "
-                         "workgroup (default); winograd = same arithmetic, 32 per workgroup; direct = 9-tap implicit GEMM")
+                         "workgroup (default); direct = 9-tap implicit GEMM")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 = the reference's arithmetic (the headline metric); f16 = BASELINE configs[4] (half storage, "
                          "fp16 MFMA with fp32 accumulators) — a different numerical contract, reported for that config only")

@@ -36,10 +36,31 @@ def extract_state_dict(ckpt, key_candidates: Sequence[str] = ("generator", "stat
     return out
 
 
+def _read_checkpoint_file(path: str) -> Mapping:
+    """Checkpoint file -> flat state_dict of CPU tensors.
+
+    The torch-free reader (ckpt.py: closed unpickling allow-list, nothing in the file can execute) handles the zip
+    format every torch >= 1.6 writes.  Only when the file is NOT such an archive (the pre-1.6 legacy stream, for which
+    the reader raises its explicit ValueError / zipfile.BadZipFile) does torch.load take over — with
+    weights_only=True, so no pickle in the file gets to run code either way.  Every other failure (a checkpoint that
+    references a disallowed global, a truncated storage, out-of-range strides) propagates: it is a bad file, not a
+    reason to try a more permissive loader."""
+    import zipfile
+
+    from .ckpt import read_state_dict
+
+    try:
+        return {k: torch.from_numpy(v) for k, v in read_state_dict(path).items()}
+    except (ValueError, zipfile.BadZipFile) as e:
+        logger.info("%s is not a zip checkpoint (%s): reading the legacy format with torch.load(weights_only=True)", path, e)
+        return extract_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
+
 def load_state_safely(model: torch.nn.Module, checkpoint_path: str,
                       key_candidates: Sequence[str] = ("generator", "state_dict", "G")) -> None:
-    """torch.load -> extract_state_dict -> load_state_dict(strict=False) -> eval()  (app.py:257-274)."""
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    """torch.load -> extract_state_dict -> load_state_dict(strict=False) -> eval()  (app.py:257-274).
+    weights_only=True: the trainer's checkpoint (training.py:359-376) holds only tensors and plain containers."""
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     model.load_state_dict(extract_state_dict(ckpt, key_candidates), strict=False)
     model.eval()
     logger.info("Loaded PyTorch weights from %s", checkpoint_path)
@@ -56,13 +77,7 @@ def load(source: Union[str, Mapping, None] = None, device: Optional[Union[str, t
         raise RuntimeError("celebrity_image_denoiser_amd.load: an AMD GPU is required (no CPU fallback)")
     model = DenoiseGenerator()
     if isinstance(source, str):
-        try:   # torch-free reader first (closed allow-list, nothing in the file can execute): ckpt.py
-            from .ckpt import read_state_dict
-
-            state = {k: torch.from_numpy(v) for k, v in read_state_dict(source).items()}
-        except Exception:   # legacy (non-zip) formats
-            state = extract_state_dict(torch.load(source, map_location="cpu", weights_only=False))
-        model.load_state_dict(state, strict=strict)
+        model.load_state_dict(_read_checkpoint_file(source), strict=strict)
     elif source is not None:
         sd = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in extract_state_dict(source).items()}
         model.load_state_dict(sd, strict=strict)

@@ -30,9 +30,19 @@ class _StorageType:
 
 
 def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
-    size, stride = tuple(size), tuple(stride)
+    size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+    storage_offset = int(storage_offset)
+    # size/stride/offset come from the file: every element they address must lie inside the storage
+    if len(size) != len(stride) or storage_offset < 0 or any(v < 0 for v in size) or any(v < 0 for v in stride):
+        raise pickle.UnpicklingError("tensor with negative or inconsistent size/stride/offset in checkpoint")
+    if all(v > 0 for v in size):
+        last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
+        if last >= storage.size:
+            raise pickle.UnpicklingError("tensor view reaches past the end of its storage")
     if len(size) == 0:
         return np.array(storage[storage_offset], dtype=storage.dtype)
+    if any(v == 0 for v in size):
+        return np.empty(size, dtype=storage.dtype)
     itemsize = storage.dtype.itemsize
     view = np.lib.stride_tricks.as_strided(storage[storage_offset:], shape=size, strides=tuple(s * itemsize for s in stride))
     return np.array(view)   # own, contiguous copy

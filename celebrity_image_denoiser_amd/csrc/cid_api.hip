@@ -4,7 +4,6 @@
 // Layer table = the reference module's declaration order, backend/app.py:42-78.
 #include "../../include/cid.h"
 #include "conv_kernels.h"
-#include "wino_kernels.h"
 #include "wino64_kernels.h"
 #include "conv_kernels_f16.h"
 
@@ -42,13 +41,9 @@ const char* kWino64KernelNames[NL] = {
     "k_wino64_conv<128, 256, false,", "k_wino64_conv<256, 256, false,", nullptr, "k_wino64_conv<256, 128, false,",
     "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
 };
-const char* kWinoKernelNames[NL] = {
-    nullptr, "k_wino_conv<64, 64, true,", "k_wino_conv<64, 128, false,", "k_wino_conv<128, 128, true,",
-    "k_wino_conv<128, 256, false,", "k_wino_conv<256, 256, false,", nullptr, "k_wino_conv<256, 128, false,",
-    "k_wino_conv<128, 128, false,", nullptr, "k_wino_conv<128, 64, false,", nullptr,
-};
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline unsigned long long cdiv_ull(unsigned long long a, unsigned long long b) { return (a + b - 1) / b; }
 
 size_t ref_weight_count(const LayerDef& L) { return (size_t)L.cin * L.cout * (L.kind == CONVT ? 4 : 9); }
 size_t packed_weight_count(const LayerDef& L) {
@@ -64,7 +59,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u2_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[4], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -84,14 +79,8 @@ struct BlobLayout {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
             raw_b_off[l] = o; o = align_up(o + kLayers[l].cout, 64);
         }
-        tab_off[0] = o; o = align_up(o + wino_slot_table(32, 2, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
-        tab_off[1] = o; o = align_up(o + wino_slot_table(16, 4, nullptr), 64);
-        tab_off[2] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // k_wino64_conv: half as many tile rows per workgroup
-        tab_off[3] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
-        for (int l = 0; l < NL; ++l) {   // U again, in k_wino64_conv's order
-            u2_off[l] = o;
-            if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 16, 64);
-        }
+        tab_off[0] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
+        tab_off[1] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
         total = o;
     }
 };
@@ -132,11 +121,10 @@ size_t ref_index(const LayerDef& L, int co, int ci, int kh, int kw) {
 }
 
 // Winograd F(2x2,3x3) filter transform U = G g G^T (reference Conv2d weight [Cout,Cin,3,3] -> 16 values per
-// (co, ci)), in double, rounded once to fp32, laid out for wino_kernels.h:
-//   [nb = co/32][chunk = ci/16][round = (ci/8)%2][a][e][lane = 32*h + j][b],  ci = 16*chunk + 8*round + 4*h + e, co = 32*nb + j
+// (co, ci)), in double, rounded once to fp32, laid out for k_wino64_conv:
+//   [nb = co/64][chunk = ci/16][round = (ci/8)%2][a][nt = (co/32)%2][e][lane = 32*h + j][b],  ci = 16*chunk + 8*round + 4*h + e, co = 64*nb + 32*nt + j
 // (one 16-byte quad per lane = the four positions b of k-step e, so a quad's registers free up after 4 MFMAs)
-// dst2 (k_wino64_conv): [nb = co/64][chunk][round][a][nt = (co/32)%2][e][lane = 32*h + j][b]
-void pack_winograd_u(const LayerDef& L, const float* w, float* dst, float* dst2) {
+void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = L.cin / 16;
     for (int co = 0; co < L.cout; ++co)
@@ -149,8 +137,7 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst, float* dst2)
             for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 4; ++b) {
                     const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
-                    dst[((((((size_t)nb * nchunk + ck) * 2 + g2) * 4 + a) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
-                    dst2[(((((((size_t)(nb >> 1) * nchunk + ck) * 2 + g2) * 4 + a) * 2 + (nb & 1)) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
+                    dst[(((((((size_t)(nb >> 1) * nchunk + ck) * 2 + g2) * 4 + a) * 2 + (nb & 1)) * 4 + e) * 64 + h * 32 + j) * 4 + b] = (float)u;
                 }
         }
 }
@@ -178,6 +165,25 @@ bool make_dims(int N, int H, int W, Dims& d) {
     return true;
 }
 
+// Why an [N,3,H,W] forward is not accepted, or nullptr.  Besides the reference's own limit (H, W >= 4: ATen raises "Output
+// size is too small", app.py:80-103) there are two of this implementation's:
+//   * the kernels address ONE image's activations through a raw buffer descriptor with 32-bit byte offsets, and a lane
+//     that must deliver zeros (convolution padding, ragged tiles) carries the offset 0x7ffffff0, which has to lie beyond
+//     the descriptor's range.  The widest per-image tensor is cat1 = [4*(H/4), 4*(W/4), 128] fp32 (512 bytes per pixel);
+//   * tile decode divides by multiply-high with 32-bit reciprocals: exact while (tiles) x (tiles per image) < 2^32; the
+//     finest tiling of any launch is k_wino64_conv's at full resolution, 2 rows x 64 columns per tile.
+// Larger inputs are an error (CID_ERR_SHAPE), never wrong results: split the batch, or the image into stripes
+// (api.serve_u8 does).
+constexpr unsigned long long kZeroSentinel = 0x7ffffff0ull;
+const char* shape_error(int N, int H, int W, Dims& d) {
+    if (!make_dims(N, H, W, d)) return "N >= 1 and H, W >= 4 required (output size is too small)";
+    if ((unsigned long long)H * W * 512ull >= kZeroSentinel)
+        return "image too large for one call: H*W must stay below 4,194,303 pixels (32-bit per-image addressing); split it into stripes";
+    const unsigned long long t0 = (unsigned long long)cdiv_ull(W, 64) * cdiv_ull(H, 2) + (unsigned long long)cdiv_ull(W, TILE_W) * cdiv_ull(H, TILE_H);
+    if ((unsigned long long)N * t0 * t0 >= (1ull << 32)) return "batch x image too large for one call (split the batch)";
+    return nullptr;
+}
+
 // activation arena (floats), NHWC
 enum Buf { T0, CAT1, P1, T1, CAT2, P2, T2, BT, T3, D2, T4, NBUF };
 struct Plan { size_t off[NBUF]; size_t total_bytes; };
@@ -199,15 +205,13 @@ struct cid_handle_s {
     const float* dev_blob = nullptr;
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
-    int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: 0 = direct implicit GEMM, 1 / 2 = Winograd F(2x2,3x3), 32 / 64 channels per workgroup
+    int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: CID_ALGO_DIRECT (9-tap implicit GEMM) or Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
     cid_handle_s() : staging(kBlob.total, 0.f) {
         std::memset(have, 0, sizeof(have));
-        wino_slot_table(32, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
-        wino_slot_table(16, 4, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
-        wino_slot_table(32, 1, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[2]));
-        wino_slot_table(16, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[3]));
+        wino_slot_table(32, 1, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
+        wino_slot_table(16, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
     }
 };
 
@@ -266,17 +270,6 @@ hipError_t launch_gemm(hipStream_t s, const float* blob, int layer, const float*
 }
 
 template <int CIN, int COUT, bool POOL, int TC>
-hipError_t launch_wino_tc(hipStream_t s, const WinoArgs& base) {
-    WinoArgs a = base;
-    constexpr int BTR = 2 * (32 / TC);
-    a.tiles_x = cdiv(a.Wc, 2 * TC); a.tiles_y = cdiv(a.Hc, 2 * BTR);
-    a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
-    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN)), dim3(THREADS), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int CIN, int COUT, bool POOL, int TC>
 hipError_t launch_wino64_tc(hipStream_t s, const WinoArgs& base) {
     WinoArgs a = base;
     constexpr int TRW = 32 / TC;
@@ -300,13 +293,8 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
-    if (algo == CID_ALGO_WINOGRAD64) {
-        a.u = blob + kBlob.u2_off[layer];
-        a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 2 : 3]);
-        return Wc > 32 ? launch_wino64_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino64_tc<CIN, COUT, MODE == 1, 16>(s, a);
-    }
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
-    return Wc > 32 ? launch_wino_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino_tc<CIN, COUT, MODE == 1, 16>(s, a);
+    return Wc > 32 ? launch_wino64_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino64_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
 
 template <int CIN, int COUT, int MODE>
@@ -364,16 +352,10 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     if (!in || !out || !ws) return fail(h, CID_ERR_INVALID, "cid_forward: null pointer");
     if (!h->dev_blob) return fail(h, CID_ERR_STATE, "cid_forward: no device weights attached (call cid_upload_weights or cid_attach_weights)");
     Dims d;
-    if (!make_dims(N, H, W, d)) {
-        char m[128];
-        std::snprintf(m, sizeof m, "cid_forward: input [%d,3,%d,%d] not accepted: N >= 1 and H, W >= 4 required (output size is too small)", N, H, W);
+    if (const char* why = shape_error(N, H, W, d)) {
+        char m[256];
+        std::snprintf(m, sizeof m, "cid_forward: input [%d,3,%d,%d] not accepted: %s", N, H, W, why);
         return fail(h, CID_ERR_SHAPE, m);
-    }
-    {   // tile decode divides by multiply-high with 32-bit reciprocals: exact while (M tiles) x (tiles per image) < 2^32
-        // the finest tiling of any launch is k_wino64_conv's at full resolution: 2 rows x 64 columns per tile
-        const unsigned long long t0 = (unsigned long long)cdiv(W, 64) * cdiv(H, 2) + (unsigned long long)cdiv(W, TILE_W) * cdiv(H, TILE_H);
-        if ((unsigned long long)N * t0 * t0 >= (1ull << 32))
-            return fail(h, CID_ERR_SHAPE, "cid_forward: batch x image too large for one call (split the batch)");
     }
     const Plan p = make_plan(d);
     if (ws_bytes < p.total_bytes) return fail(h, CID_ERR_WORKSPACE, "cid_forward: workspace smaller than cid_workspace_bytes()");
@@ -491,7 +473,7 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         float* dst = h->staging.data() + kBlob.w_off[l];
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
         std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
-        if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l], h->staging.data() + kBlob.u2_off[l]);
+        if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l]);
         if (L.kind == TAIL) {   // half copy for k_conv_tail_h: [k-step s][lane = 32*h + col][e], ci = 16*s + 8*h + e, col = 3*tap + co
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
@@ -579,7 +561,7 @@ int cid_out_shape(int H, int W, int* Ho, int* Wo) {
 int cid_workspace_bytes(int N, int H, int W, size_t* bytes) {
     if (!bytes) return CID_ERR_INVALID;
     Dims d;
-    if (!make_dims(N, H, W, d)) return CID_ERR_SHAPE;
+    if (shape_error(N, H, W, d)) return CID_ERR_SHAPE;
     *bytes = make_plan(d).total_bytes;
     return CID_OK;
 }
@@ -658,12 +640,12 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
     if (h && h->algo == CID_ALGO_WINOGRAD64 && kWino64KernelNames[i]) return kWino64KernelNames[i];
-    return (h && h->algo == CID_ALGO_WINOGRAD && kWinoKernelNames[i]) ? kWinoKernelNames[i] : kKernelNames[i];
+    return kKernelNames[i];
 }
 
 int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
-    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD && algo != CID_ALGO_WINOGRAD64) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
+    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
     return CID_OK;
 }

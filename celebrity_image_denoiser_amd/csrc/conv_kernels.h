@@ -213,6 +213,9 @@ __device__ __forceinline__ void wide_store_h_full(float* stg, int lane, ValFn va
 //   bit 4 (results stay correct, MODE 2): wave 0 writes s_memtime stamps and HW_ID to a.pool (layer_bench <N> trace, tools/trace_stats.py)
 template <int CIN, int COUT, int MODE, int ABLATE = 0, int WPS = 2>
 __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     constexpr int TAPS = (MODE == 2) ? 1 : 9;
     constexpr int HALO = (MODE == 2) ? 0 : 1;
     constexpr int LW = TILE_W + 2 * HALO;            // LDS tile width in pixels
@@ -284,14 +287,6 @@ __global__ void __launch_bounds__(THREADS, WPS) k_gemm_conv(const GemmConvArgs a
     };
 
     f32x16 acc[2][2];   // first written by the zero-C MFMAs of chunk 0
-
-    // A fragment base pixel of (row 2*wave+m, column i) inside the LDS tile, tap (0,0)    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
 
     // A fragment base pixel of (row 2*wave+m, column i) inside the LDS tile, tap (0,0)
     const int pbase0 = (2 * wave) * LW + i;
@@ -486,6 +481,9 @@ struct HeadArgs {
 // ABLATE (timing experiments only, tools/headtail_bench.hip; wrong results when non-zero): 1 no input loads, 2 no MFMAs, 4 no stores.
 template <bool IN_U8, bool OUT_F16 = false, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;   // 34 used columns, padded to 36
     constexpr int STG16 = 16 * WS_STRIDE;                      // store staging per wave: 16 pixels x 64 channels
     __shared__ __attribute__((aligned(16))) float lds[3 * PLANE + 4 * STG16];   // input planes | store staging (21.7 KB)
@@ -635,6 +633,9 @@ inline void tail_groups(TailArgs& a) {
 // 0.17 ms of the 0.30 ms this kernel took when it ran load -> product -> load -> product -> epilogue).
 template <bool OUT_U8, bool IN_F16 = false, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_conv_tail(const TailArgs a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;   // 340 halo pixels
     constexpr int MT = (LPIX + 31) / 32, LP = MT * 32;                // 11 M tiles, 352 rows
     constexpr int NSLOT = LPIX * 8, NLOAD = (NSLOT + THREADS - 1) / THREADS;

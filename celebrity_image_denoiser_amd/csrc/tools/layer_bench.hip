@@ -1,9 +1,8 @@
 // layer_bench.hip — timing experiments on single layers of the forward (not part of the product).
-// Build: make -C celebrity-image-denoiser_amd/csrc tools     Run on the GPU box: ./layer_bench
+// Build: make -C celebrity_image_denoiser_amd/csrc tools     Run on the GPU box: ./layer_bench
 // Each variant is run ROUNDS times, interleaved with the others in one process; prints median ms
 // and algorithmic TFLOP/s.  ABLATE variants compute wrong results by design (see conv_kernels.h).
 #include "../conv_kernels.h"
-#include "../wino_kernels.h"
 #include "../wino64_kernels.h"
 #include <algorithm>
 #include <cstdio>
@@ -38,29 +37,6 @@ static Variant make(const char* name, int N, int H, int W, float* in, float* w, 
     const int grid = 8 * a.tiles_per_xcd * NB;
     const double flops = 2.0 * CIN * COUT * (MODE == 2 ? 4 : 9) * (double)N * H * W;
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_gemm_conv<CIN, COUT, MODE, ABLATE, WPS>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
-}
-
-template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
-static Variant makew(const char* name, int N, int H, int W, float* in, float* u, float* bias, float* out, float* pool) {
-    WinoArgs a{};
-    a.in = in; a.u = u; a.bias = bias; a.out = out; a.pool = pool;
-    static unsigned* tabs[2] = {nullptr, nullptr};
-    const int ti = TC == 32 ? 0 : 1;
-    if (!tabs[ti]) {
-        std::vector<unsigned> h(wino_slot_table(TC, 2 * (32 / TC), nullptr));
-        wino_slot_table(TC, 2 * (32 / TC), h.data());
-        CK(hipMalloc(&tabs[ti], h.size() * 4));
-        CK(hipMemcpy(tabs[ti], h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    }
-    a.slot_tab = tabs[ti];
-    a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
-    constexpr int BTR = 2 * (32 / TC);
-    a.tiles_x = (W + 2 * TC - 1) / (2 * TC); a.tiles_y = (H + 2 * BTR - 1) / (2 * BTR);
-    a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
-    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    const int grid = 8 * a.tiles_per_xcd * (COUT / WN) / ((ABLATE & 128) ? 2 : 1);
-    const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;   // algorithmic (direct) FLOPs
-    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
 }
 
 template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
@@ -104,17 +80,6 @@ int main(int argc, char** argv) {
     float* uA = dalloc((size_t)128 * 64 * 16, 0.05f);
     float* uB = dalloc((size_t)256 * 256 * 16, 0.05f);
     v.push_back(make<128, 64, 0, 0, 2>("A direct 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 0>("A wino base", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 128>("A wino 2-items/WG", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 128 + 15>("A wino mfma-only 2-items/WG", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 64>("A wino no-stagger", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 1>("A wino no-halo-prefetch", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 2>("A wino no-B-loads", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 4>("A wino no-A-build", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 16>("A wino A-read-no-xform", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 8>("A wino no-epilogue", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 7>("A wino mfma+epilogue", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew<128, 64, false, 32, 15>("A wino mfma-only", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 0>("A wino64 base", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 1>("A wino64 no-dma", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 2>("A wino64 no-B-loads", N, 128, 128, inA, uA, bA, outA, poolA));
@@ -129,10 +94,6 @@ int main(int argc, char** argv) {
     v.push_back(make<256, 256, 0, 0, 2>("B direct 256->256@32", N, 32, 32, inB, wB, bB, outB, nullptr));
     v.push_back(makew64<256, 256, false, 16, 0>("B wino64 base", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew64<256, 256, false, 16, 15>("B wino64 mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
-    v.push_back(makew<256, 256, false, 16, 0>("B wino base", N, 32, 32, inB, uB, bB, outB, nullptr));
-    v.push_back(makew<256, 256, false, 16, 64>("B wino no-stagger", N, 32, 32, inB, uB, bB, outB, nullptr));
-    v.push_back(makew<256, 256, false, 16, 2>("B wino no-B-loads", N, 32, 32, inB, uB, bB, outB, nullptr));
-    v.push_back(makew<256, 256, false, 16, 15>("B wino mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
     {   // up1 shape: ConvT 128 -> 64 on 64x64 inputs (output 128x128x64); reuse inA (>= N*64*64*128) and outA
         v.push_back(make<128, 64, 2, 0, 2>("T convT 128->64@64 base", N, 64, 64, inA, wA, bA, outA, nullptr));
         v.push_back(make<128, 64, 2, 1, 2>("T no-halo-prefetch", N, 64, 64, inA, wA, bA, outA, nullptr));

@@ -1,27 +1,67 @@
-// wino64_kernels.h — Winograd F(2x2,3x3) 3x3 convolution, second decomposition: 32 tiles x 64 output channels per
-// workgroup, one row of the transformed tile per wave.
+// wino64_kernels.h — 3x3 convolution (+bias, +ReLU, +optional 2x2 max-pool) as Winograd F(2x2,3x3) on the exact-f32
+// matrix instruction v_mfma_f32_32x32x2_f32 (gfx950): 32 tiles x 64 output channels per workgroup, one row of the
+// transformed tile per wave.
 //
-// Same function, same arithmetic and the same summation order as k_wino_conv (wino_kernels.h: see there for the
-// algorithm, the LDS pixel order, the LDS-DMA and the B stream); what changes is who owns what:
-//   * k_wino_conv:   wave = 2 rows a x 4 positions b x ONE 32-channel column block; every A operand (a V value, built
-//                    with 2 VALU instructions) feeds one MFMA.
-//   * k_wino64_conv: wave = ONE row a (= its wave index) x 4 positions b x TWO 32-channel column blocks; every A
-//                    operand feeds two MFMAs.  Per MFMA that is half the transform VALU and LDS reads, and 2/3 of the
-//                    halo DMA (the workgroup's raw tile is 2*TRW+2 rows for TRW tile rows instead of 4*TRP+2 for 2*TRP).
-//     VALU instructions beside the MFMA stream cost matrix-pipe time beyond ~1 per MFMA (tools/mix_bench); this
-//     decomposition sits at 1.
+// Computes the same function as the reference's nn.Conv2d(k=3, p=1) + nn.ReLU (+ nn.MaxPool2d(2,2)) stages
+// (backend/app.py:43-77) with 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36: for each of the 16
+// positions xi = (a, b) of the transformed 4x4 tile,
+//       M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co],     V = B^T d B,  U = G g G^T,     Y(2x2) = A^T M A.
+// U is computed on the host at load time (cid_api.hip, in double, rounded once).  V is never stored: each lane rebuilds
+// the four V values of a row `a` from eight 16-byte LDS reads of the raw input tile (adds only).
+//
+//   * wave w = row a = w of B^T d B x 4 positions b x TWO 32-channel column blocks (8 accumulator tiles = 128 VGPRs):
+//     every A operand feeds two MFMAs, i.e. 1 VALU instruction and 1/4 ds_read_b128 per MFMA.  VALU instructions beside
+//     the MFMA stream cost matrix-pipe time beyond ~1 per MFMA (tools/mix_bench); this decomposition sits at 1.
+//   * K is walked in 16-channel chunks through a double-buffered raw halo tile in LDS (pixel = 4 data slots + 1 pad slot
+//     of 16 B; inside a tile row even columns first, then odd columns: conflict-free ds_read_b128); the next chunk is
+//     written by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write; out-of-image and pad slots carry an
+//     out-of-range offset and the buffer range check writes zeros).
 //   A unit = row a, 8 input channels, both column blocks = 32 MFMAs; a 16-channel chunk = 2 units.
 //   * B: 8 quads (column block nt, k-step e) per unit, each refilled for the NEXT unit right after its four MFMAs.
 //   * raw tile double-buffered; the DMA of chunk c+2 is issued at the start of unit 1 of chunk c (its buffer was last
 //     read during unit 0) and must have landed by the one barrier of chunk c+1, at the end of its unit 0: two units
 //     (>= 4096 cycles) of slack.
 //   * epilogue: the four waves exchange their column-transformed rows m'[a] through LDS; wave w then finishes column
-//     block w>>1, tiles 16*(w&1) .. +16: Y[0] = (m'0 + m'1) + m'2, Y[1] = m'1 - (m'2 + m'3) (the order k_wino_conv uses,
-//     so both kernels return the same bits), bias, ReLU, optional 2x2 max-pool, 16-byte stores via LDS staging.
+//     block w>>1, tiles 16*(w&1) .. +16: Y[0] = (m'0 + m'1) + m'2, Y[1] = m'1 - (m'2 + m'3), bias, ReLU, optional 2x2 max-pool, 16-byte stores via LDS staging.
 #pragma once
-#include "wino_kernels.h"
+#include "conv_kernels.h"
 
 namespace cid {
+
+constexpr int WK = 16;        // channels per chunk
+constexpr int WPS = 5;        // LDS slots (16 B) per pixel: 4 data + 1 pad
+constexpr int WS32 = 36;      // staging row stride (floats) for 32-channel slabs
+
+// Host: the slot table of k_wino64_conv<.., TC>: LDS slot s (16 B) of the raw halo tile -> packed (row, column, group).
+// Must mirror the kernel's LDS order: pixel = s/5 (4 data slots + 1 pad), rows of LWS pixels, even columns then odd.
+// BTR = tile rows per workgroup = 32/TC.
+inline int wino_slot_table(int TC, int BTR, unsigned* out /* may be null */) {
+    const int LW = 2 * TC + 2, LH = 2 * BTR + 2, LWS = (TC == 16) ? 40 : LW, HWD = LWS / 2;
+    // padded to 4 * RW rounds (RW = rounds per wave), so that every wave reads RW entries unconditionally: a guarded
+    // load compiles to load -> wait -> next load, i.e. RW serialised memory latencies in every workgroup's prologue
+    const int LPIX = LWS * LH, NROUND = (LPIX * WPS + 63) / 64, RW = (NROUND + 3) / 4;
+    if (out)
+        for (int s = 0; s < 4 * RW * 64; ++s) {
+            const int p = s / WPS, c = s - p * WPS;
+            const int hy = p / LWS, rem = p - hy * LWS, plane = rem / HWD, hx = 2 * (rem - plane * HWD) + plane;
+            out[s] = (s < NROUND * 64 && c < 4 && p < LPIX && hx < LW) ? ((unsigned)hy << 20 | (unsigned)hx << 8 | (unsigned)c) : ~0u;
+        }
+    return 4 * RW * 64;
+}
+
+struct WinoArgs {
+    const float* in;    // NHWC [N, Hin, Win, in_ps]
+    const float* u;     // packed U: [nb][chunk][round][a][nt][e][lane][b]  (cid_api.hip pack_winograd_u)
+    const float* bias;  // [COUT]
+    const unsigned* slot_tab;   // per LDS slot of the raw tile: (row << 20 | column << 8 | channel group), ~0u = deliver zeros (host: wino_slot_table)
+    float* out;         // [N, Hs, Ws, out_ps] (+ out_coff)
+    float* pool;        // POOL: [N, Hc/2, Wc/2, COUT]
+    int N, Hin, Win, in_ps;
+    int Hc, Wc, Hs, Ws;
+    int out_ps, out_coff;
+    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
+};
 
 constexpr int WN2 = 64;       // output channels per workgroup
 
@@ -30,9 +70,14 @@ constexpr int WN2 = 64;       // output channels per workgroup
 // barrier, 64 no prologue DMA, 128 no de-phasing of the two workgroups of a CU, 256 s_memtime trace into a.pool (results stay correct).
 template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     constexpr int TRW = 32 / TC;                 // tile rows per workgroup
     constexpr int LW = 2 * TC + 2, LH = 2 * TRW + 2;
-    constexpr int LWS = (TC == 16) ? 40 : LW;    // see k_wino_conv: two tile rows in one 32-lane read
+    // LDS row stride in pixels.  TC=16 puts two tile rows in one 32-lane read; their slot offset (2 rows x LWS x 5 slots) must be
+    // a multiple of 16 slots or the two half-rows collide in ds_read_b128's bank columns: 34 -> 40.
+    constexpr int LWS = (TC == 16) ? 40 : LW;
     constexpr int LPIX = LWS * LH;
     constexpr int NROUND = (LPIX * WPS + 63) / 64;
     constexpr int RW = (NROUND + 3) / 4;
@@ -46,11 +91,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     // one piece after each of them.  Same-box A/B, layer by layer: the interleaved form gains 0.5-2 % on the layers with
     // CIN >= 128 and loses 1.5-4 % on the two with CIN = 64.
     constexpr bool INTERLEAVE = CIN >= 128;
-#ifdef CID_DMA_PER_GROUP
-    constexpr int DMA_PER_GROUP = CID_DMA_PER_GROUP;
-#else
     constexpr int DMA_PER_GROUP = CIN <= 128 ? 1 : 2;
-#endif
     static_assert(CIN % WK == 0 && COUT % WN2 == 0 && (TC == 16 || TC == 32), "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
     constexpr int LDS_SLOTS_K = 4096;            // 64 KiB: 2 raw buffers, later the 4x4 exchange blocks, later store staging
@@ -79,7 +120,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     }
     const float bias_v = a.bias[nb * WN2 + (wave >> 1) * 32 + i];   // epilogue role of wave w: column block w>>1, tiles 16*(w&1)..+16
 
-    if (blockIdx.x < 2 * 256) {   // de-phase the two workgroups of a CU once (see k_wino_conv)
+    if (blockIdx.x < 2 * 256) {   // de-phase the two workgroups of a CU once
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         // Measured on this kernel (tools/layer_bench): without the de-phasing 2.40 ms, with it 2.27 ms (upconv1.0 shape).
@@ -97,7 +138,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     const int xb = (pbase + xrow * LWS) * WPS + h, yb = (pbase + yrow * LWS) * WPS + h;
     auto col_off = [](int c) { return ((c & 1) * HWD + (c >> 1)) * WPS; };
 
-    // ---- LDS-DMA sources (as k_wino_conv) ----
+    // ---- LDS-DMA sources ----
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
     unsigned voff[RW];
@@ -367,7 +408,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
 #pragma unroll
             for (int arow = 0; arow < 4; ++arow) m[arow] = (arow == W) ? own[rr] : ex[(arow * 4 + W) * 512 + rr * 64 + lane];
 #pragma unroll
-            for (int bp = 0; bp < 2; ++bp) {   // the summation order of k_wino_conv: same bits from both kernels
+            for (int bp = 0; bp < 2; ++bp) {   // fixed summation order (golden outputs depend on it)
                 y[0][bp][rr] = (m[0][bp] + m[1][bp]) + m[2][bp];
                 y[1][bp][rr] = m[1][bp] - (m[2][bp] + m[3][bp]);
             }

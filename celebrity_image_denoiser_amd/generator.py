@@ -64,6 +64,8 @@ class DenoiseGenerator(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def _signature(self):
+        # p._version counts in-place updates made through the tensor API; writes through `p.data` or raw pointers do not
+        # bump it — after such a write call pack_weights(force=True).
         return tuple((k, p.data_ptr(), p._version, str(p.device)) for k, p in self.named_parameters())
 
     def _device(self) -> torch.device:
@@ -154,14 +156,22 @@ class DenoiseGenerator(nn.Module):
             # the reference fails here too (ATen: "Output size is too small")
             raise RuntimeError(f"Given input size: ({h}x{w}). Calculated output size is too small (H and W must be >= 4)")
         self.pack_weights()
-        need = ctypes.c_size_t()
-        _lib.check(self._cid, L.cid_workspace_bytes(n, h, w, ctypes.byref(need)))
-        if self._ws is None or self._ws.numel() < need.value or self._ws.device != x.device:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        self._ensure_arena(n, h, w, x.device)
         x = x.contiguous()
         y = self._output(out, (n, 3, ho.value, wo.value), torch.float32, x.device)
         return x, y, n, h, w
+
+    def _ensure_arena(self, n: int, h: int, w: int, device: torch.device) -> None:
+        """Grow-only activation arena.  Replacing it waits for the device first: kernels of an earlier forward (possibly on
+        another stream, e.g. HostPipeline's compute stream) may still be using the old one, and the caching allocator
+        would hand its memory to the next allocation of the stream that owns it."""
+        need = ctypes.c_size_t()
+        _lib.check(self._cid, _lib.lib().cid_workspace_bytes(n, h, w, ctypes.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            if self._ws is not None:
+                torch.cuda.synchronize(self._ws.device)
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
 
     @staticmethod
     def _output(out, shape, dtype, device) -> torch.Tensor:
@@ -215,11 +225,7 @@ class DenoiseGenerator(nn.Module):
         if n < 1 or L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) != _lib.CID_OK:
             raise RuntimeError(f"Given input size: ({h}x{w}). Calculated output size is too small (H and W must be >= 4)")
         self.pack_weights()
-        need = ctypes.c_size_t()
-        _lib.check(self._cid, L.cid_workspace_bytes(n, h, w, ctypes.byref(need)))
-        if self._ws is None or self._ws.numel() < need.value or self._ws.device != x.device:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        self._ensure_arena(n, h, w, x.device)
         x = x.contiguous()
         if out_u8:
             y = self._output(out, (n, ho.value, wo.value, 3), torch.uint8, x.device)
@@ -245,17 +251,17 @@ class DenoiseGenerator(nn.Module):
 
     @property
     def conv_algo(self) -> str:
-        """"winograd64" (default; Winograd F(2x2,3x3) on MFMA, 64 output channels per workgroup), "winograd" (the same
-        arithmetic and bits, 32 output channels per workgroup) or "direct" (9-tap implicit GEMM) for the 3x3 GEMM layers."""
+        """"winograd64" (default; Winograd F(2x2,3x3) on MFMA, 64 output channels per workgroup) or "direct" (9-tap
+        implicit GEMM) for the eight 3x3 GEMM layers."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
-        return {_lib.CID_ALGO_WINOGRAD: "winograd", _lib.CID_ALGO_WINOGRAD64: "winograd64"}.get(a.value, "direct")
+        return "winograd64" if a.value == _lib.CID_ALGO_WINOGRAD64 else "direct"
 
     @conv_algo.setter
     def conv_algo(self, name: str) -> None:
-        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd": _lib.CID_ALGO_WINOGRAD, "winograd64": _lib.CID_ALGO_WINOGRAD64}.get(name)
+        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd64": _lib.CID_ALGO_WINOGRAD64}.get(name)
         if algo is None:
-            raise ValueError("conv_algo must be 'direct', 'winograd' or 'winograd64'")
+            raise ValueError("conv_algo must be 'direct' or 'winograd64'")
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
     @property

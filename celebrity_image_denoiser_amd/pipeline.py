@@ -136,6 +136,8 @@ class HostPipeline:
             raise ValueError("iterations must be >= 1")
         pending: List[_Slot] = []
         k = 0
+        # the model's arena is shared with eager calls on the caller's stream: order this run's forwards behind them
+        self.s_fw.wait_stream(torch.cuda.current_stream(self.dev))
         try:
             for batch in batches:
                 slot = self.slots[k % self.depth]
@@ -180,20 +182,41 @@ class GraphedForward:
         self.model = model
         self.u8 = example.dtype == torch.uint8
         self.static_in = example.clone().contiguous()
-        model.forward_fmt(self.static_in, out_u8=self.u8)        # packs weights, sizes the arena: nothing allocates in the capture
-        torch.cuda.synchronize(example.device)
-        self.graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(example.device)
-        side.wait_stream(torch.cuda.current_stream(example.device))
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(self.graph, stream=side):
-                self.static_out = model.forward_fmt(self.static_in, out_u8=self.u8)
-        torch.cuda.current_stream(example.device).wait_stream(side)
+        self._capture()
+
+    def _capture(self) -> None:
+        """Capture one forward.  The graph bakes in raw device addresses, so everything it touches is owned here: the
+        input/output tensors, a PRIVATE activation arena (the model's own may be replaced when a later eager call needs a
+        bigger one) and a reference to the packed weights blob it was captured with (a parameter update makes the model
+        pack a new blob; `__call__` notices and re-captures)."""
+        model, dev = self.model, self.static_in.device
+        self._blob = model.pack_weights()
+        self._sig = model._packed_sig
+        shape = self.static_in.shape
+        n, h, w = (shape[0], shape[1], shape[2]) if self.u8 else (shape[0], shape[2], shape[3])
+        shared, model._ws = model._ws, None
+        try:
+            model._ensure_arena(n, h, w, dev)
+            self._ws = model._ws                                     # the graph's own arena
+            model.forward_fmt(self.static_in, out_u8=self.u8)        # warm: nothing allocates inside the capture
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.static_out = model.forward_fmt(self.static_in, out_u8=self.u8)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            assert model._ws is self._ws and model._blob is self._blob
+        finally:
+            model._ws = shared
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
             raise RuntimeError(f"GraphedForward was captured for {self.static_in.dtype} {list(self.static_in.shape)} on "
                                f"{self.static_in.device}, got {x.dtype} {list(x.shape)} on {x.device}")
+        if self.model.pack_weights() is not self._blob or self.model._packed_sig != self._sig:
+            self._capture()                                          # the weights changed since the capture
         self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out

@@ -151,12 +151,12 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
 /*
  * Algorithm of the eight GEMM-shaped 3x3 convolutions (down1[2] ... upconv1[0]); head, tail and the
  * transposed convolutions are unaffected.  Both compute the reference's nn.Conv2d(k=3,p=1) in fp32:
- *   CID_ALGO_DIRECT   implicit GEMM, 9 taps (36 multiplies per 2x2 outputs and (ci,co))
- *   CID_ALGO_WINOGRAD   Winograd F(2x2,3x3) (16 multiplies), 32 output channels per workgroup
- *   CID_ALGO_WINOGRAD64 the same arithmetic (bit-identical results), 64 output channels per workgroup: the default
+ *   CID_ALGO_DIRECT     implicit GEMM, 9 taps (36 multiplies per 2x2 outputs and (ci,co))
+ *   CID_ALGO_WINOGRAD64 Winograd F(2x2,3x3) (16 multiplies), 64 output channels per workgroup: the default
+ * (value 1 was round 1's first Winograd kernel, removed: same bits as WINOGRAD64, slower.)
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */
-enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD = 1, CID_ALGO_WINOGRAD64 = 2 };
+enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2 };
 
 /*
  * Storage type of activations and weights between the first and the last kernel (BASELINE configs[4]):

@@ -50,6 +50,28 @@ def test_out_shape_and_workspace():
     assert L.cid_workspace_bytes(0, 128, 128, ctypes.byref(n)) == 2
 
 
+def test_oversize_image_is_an_error_not_wrong_borders():
+    """A single image whose widest per-image activation ([4*(H/4), 4*(W/4), 128] fp32) reaches the kernels' zero-padding
+    sentinel offset 0x7ffffff0 must be refused (2048x2048 was accepted and read real data as padding).
+    No GPU is touched: the shape check comes before any HIP call."""
+    L = _lib.lib()
+    n = ctypes.c_size_t()
+    for (h, w) in ((2048, 2048), (2304, 2048), (2400, 2000), (4, 1 << 20)):
+        assert L.cid_workspace_bytes(1, h, w, ctypes.byref(n)) == 2, (h, w)
+    assert L.cid_workspace_bytes(1, 2047, 2048, ctypes.byref(n)) == 0           # 2047*2048*512 < 0x7ffffff0
+    assert L.cid_workspace_bytes(1, 2000, 2000, ctypes.byref(n)) == 0
+    assert L.cid_workspace_bytes(200000, 128, 128, ctypes.byref(n)) == 2         # tile decode by multiply-high: N x tiles^2 < 2^32
+    h = ctypes.c_void_p()
+    assert L.cid_create(ctypes.byref(h)) == 0
+    fake = ctypes.c_void_p(1 << 20)                                              # aligned, never dereferenced
+    assert L.cid_attach_weights(h, fake) == 0
+    rc = L.cid_forward(h, fake, fake, 1, 2048, 2048, fake, 1 << 40, None)
+    assert rc == 2 and b"too large" in L.cid_last_error(h) and b"stripes" in L.cid_last_error(h)
+    rc = L.cid_forward(h, fake, fake, 1, 3, 3, fake, 1 << 40, None)
+    assert rc == 2 and b"too small" in L.cid_last_error(h)
+    L.cid_destroy(h)
+
+
 def test_algorithmic_work_matches_survey():
     """11,521,753,088 FLOP per 128x128 image, 46,087,012,352 per 256x256."""
     L = _lib.lib()

@@ -147,6 +147,33 @@ def test_torch_free_checkpoint_reader(tmp_path):
         zf.writestr("archive/data.pkl", pickle.dumps(os.getcwd))
     with pytest.raises(pickle.UnpicklingError):
         ckpt.read_checkpoint(evil)
+    # ... and the path-taking loader does NOT retry it with a more permissive unpickler (it used to fall back to
+    # torch.load(weights_only=False) on any exception, i.e. exactly when the allow-list had just refused the file)
+    from celebrity_image_denoiser_amd import api
+
+    with pytest.raises(pickle.UnpicklingError):
+        api._read_checkpoint_file(evil)
+    # a legacy (non-zip) checkpoint is the one case that goes to torch.load, with weights_only=True
+    legacy = os.path.join(tmp_path, "legacy.pth")
+    torch.save({"generator": {k: torch.from_numpy(v) for k, v in ref.items()}}, legacy, _use_new_zipfile_serialization=False)
+    got2 = api._read_checkpoint_file(legacy)
+    assert list(got2.keys()) == list(ref.keys()) and all(np.array_equal(got2[k].numpy(), ref[k]) for k in ref)
+
+
+def test_checkpoint_reader_bounds_checks_tensor_views(tmp_path):
+    """size/stride/offset come from the file; a view that reaches past its storage must be refused, not read
+    (as_strided without a bounds check)."""
+    import pickle
+
+    from celebrity_image_denoiser_amd import ckpt
+
+    st = np.arange(12, dtype=np.float32)
+    ok = ckpt._rebuild_tensor_v2(st, 2, (2, 3), (3, 1))
+    assert np.array_equal(ok, st[2:8].reshape(2, 3))
+    assert ckpt._rebuild_tensor_v2(st, 0, (0, 5), (5, 1)).shape == (0, 5)
+    for off, size, stride in ((0, (4, 4), (4, 1)), (8, (2, 3), (3, 1)), (0, (2,), (12,)), (-1, (2,), (1,)), (0, (2,), (-1,)), (12, (), ())):
+        with pytest.raises(pickle.UnpicklingError):
+            ckpt._rebuild_tensor_v2(st, off, size, stride)
 
 
 def test_host_pipeline_refuses_cpu_model():
