@@ -47,6 +47,12 @@ SYMBOLS = {
     "cid_debug_poison_lds": (_c.c_int, [_c.c_void_p]),
     "cid_set_compute_dtype": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_compute_dtype": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "cid_stage_view": (_c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int),
+                                  _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "cid_comm_unique_id": (_c.c_int, [_c.c_void_p]),
+    "cid_comm_init_rank": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_void_p, _c.c_int]),
+    "cid_comm_destroy": (_c.c_int, [_c.c_void_p]),
+    "cid_broadcast_weights": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "cid_launch_work": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 

@@ -7,6 +7,8 @@
 #include "wino64_kernels.h"
 #include "conv_kernels_f16.h"
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -15,6 +17,8 @@
 namespace {
 
 using namespace cid;
+
+struct ncclUniqueIdBytes { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 
 enum Kind { HEAD, CONV, CONVT, TAIL };
 struct LayerDef { const char* name; Kind kind; int cin, cout; };
@@ -678,6 +682,110 @@ int cid_debug_poison_lds(void* stream) {
 int cid_get_conv_algo(cid_handle_t h, int* algo) {
     if (!h || !algo) return CID_ERR_INVALID;
     *algo = h->algo;
+    return CID_OK;
+}
+
+// ---- where the reference module's stage outputs live in the arena (tests: per-stage parity) ----
+int cid_stage_view(const char* stage, int N, int H, int W, size_t* offset_bytes, int* C, int* Hs, int* Ws, int* pixel_stride, int* channel_offset) {
+    if (!stage || !offset_bytes || !C || !Hs || !Ws || !pixel_stride || !channel_offset) return CID_ERR_INVALID;
+    Dims d;
+    if (shape_error(N, H, W, d)) return CID_ERR_SHAPE;
+    const Plan p = make_plan(d);
+    struct Row { const char* name; Buf buf; int c, hs, ws, ps, coff; };
+    const Row rows[] = {
+        {"down1", CAT1, 64, d.Hu1, d.Wu1, 128, 64},      // e1, top-left crop Hu1 x Wu1 of H x W       app.py:81,97-100
+        {"pool1", P1, 64, d.H1, d.W1, 64, 0},            //                                            app.py:82
+        {"down2", CAT2, 128, d.Hu2, d.Wu2, 256, 128},    // e2, top-left crop Hu2 x Wu2 of H1 x W1     app.py:84,90-93
+        {"pool2", P2, 128, d.H2, d.W2, 128, 0},          //                                            app.py:85
+        {"bottleneck", BT, 256, d.H2, d.W2, 256, 0},     //                                            app.py:87
+        {"up2", CAT2, 128, d.Hu2, d.Wu2, 256, 0},        //                                            app.py:89
+        {"upconv2", D2, 128, d.Hu2, d.Wu2, 128, 0},      //                                            app.py:94
+        {"up1", CAT1, 64, d.Hu1, d.Wu1, 128, 0},         //                                            app.py:96
+    };
+    for (const Row& r : rows)
+        if (std::strcmp(stage, r.name) == 0) {
+            *offset_bytes = p.off[r.buf] * sizeof(float);
+            *C = r.c; *Hs = r.hs; *Ws = r.ws; *pixel_stride = r.ps; *channel_offset = r.coff;
+            return CID_OK;
+        }
+    return CID_ERR_KEY;
+}
+
+// ---- multi-GPU: the one collective of the job, without PyTorch in it ----
+// RCCL is bound at run time from the process (the library that created the caller's communicator), not linked: libcid.so
+// loads on a box without RCCL, and a host that already has an RCCL (PyTorch ships its own librccl.so.1) keeps exactly one.
+}  // extern "C"
+namespace {
+struct Rccl {
+    typedef int (*GetUniqueId)(void*);
+    typedef int (*CommInitRank)(void**, int, ncclUniqueIdBytes, int);
+    typedef int (*CommDestroy)(void*);
+    typedef int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*GetErrorString)(int);
+    GetUniqueId get_unique_id = nullptr; CommInitRank comm_init_rank = nullptr; CommDestroy comm_destroy = nullptr;
+    Broadcast broadcast = nullptr; GetErrorString error_string = nullptr;
+    std::string why;
+    bool ok = false;
+};
+const Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy this process already uses
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { x.why = std::string("librccl.so.1 not found: ") + dlerror(); return x; }
+        x.get_unique_id = (Rccl::GetUniqueId)dlsym(lib, "ncclGetUniqueId");
+        x.comm_init_rank = (Rccl::CommInitRank)dlsym(lib, "ncclCommInitRank");
+        x.comm_destroy = (Rccl::CommDestroy)dlsym(lib, "ncclCommDestroy");
+        x.broadcast = (Rccl::Broadcast)dlsym(lib, "ncclBroadcast");
+        x.error_string = (Rccl::GetErrorString)dlsym(lib, "ncclGetErrorString");
+        x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.broadcast && x.error_string;
+        if (!x.ok) x.why = "librccl.so.1 lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclBroadcast";
+        return x;
+    }();
+    return r;
+}
+int rccl_fail(cid_handle_t h, const char* what, int rc) {
+    return fail(h, CID_ERR_HIP, std::string(what) + ": " + (rccl().error_string ? rccl().error_string(rc) : "RCCL error"));
+}
+}  // namespace
+extern "C" {
+
+int cid_comm_unique_id(void* id128) {
+    if (!id128) return CID_ERR_INVALID;
+    if (!rccl().ok) return CID_ERR_STATE;
+    return rccl().get_unique_id(id128) == 0 ? CID_OK : CID_ERR_HIP;
+}
+int cid_comm_init_rank(void** comm, int nranks, const void* id128, int rank) {
+    if (!comm || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return CID_ERR_INVALID;
+    if (!rccl().ok) return CID_ERR_STATE;
+    ncclUniqueIdBytes id;
+    std::memcpy(&id, id128, sizeof id);
+    return rccl().comm_init_rank(comm, nranks, id, rank) == 0 ? CID_OK : CID_ERR_HIP;
+}
+int cid_comm_destroy(void* comm) {
+    if (!comm) return CID_ERR_INVALID;
+    if (!rccl().ok) return CID_ERR_STATE;
+    return rccl().comm_destroy(comm) == 0 ? CID_OK : CID_ERR_HIP;
+}
+
+int cid_broadcast_weights(cid_handle_t h, void* comm, int root, int rank, void* stream) {
+    if (!h) return CID_ERR_INVALID;
+    if (!comm || root < 0 || rank < 0) return fail(h, CID_ERR_INVALID, "cid_broadcast_weights: null communicator or negative rank");
+    if (!h->dev_blob) return fail(h, CID_ERR_STATE, "cid_broadcast_weights: no device blob attached (root: cid_upload_weights; receivers: cid_attach_weights on an allocated buffer)");
+    if (!rccl().ok) return fail(h, CID_ERR_STATE, "cid_broadcast_weights: " + rccl().why);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void* blob = const_cast<float*>(h->dev_blob);
+    const size_t bytes = kBlob.total * sizeof(float);
+    const int rc = rccl().broadcast(blob, blob, bytes, /*ncclUint8*/ 1, root, comm, s);   // in place: one 26 MB message, root -> everyone
+    if (rc != 0) return rccl_fail(h, "ncclBroadcast", rc);
+    if (rank != root) {   // receivers: refresh the host staging copy, so cid_get_weight / state_dict() return what the kernels use
+        hipError_t e = hipMemcpyAsync(h->staging.data(), blob, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(h, CID_ERR_HIP, std::string("cid_broadcast_weights: ") + hipGetErrorString(e));
+        std::memset(h->have, 1, sizeof(h->have));
+    }
     return CID_OK;
 }
 

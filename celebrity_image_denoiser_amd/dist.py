@@ -3,8 +3,8 @@
 Every image is independent in the forward (no batch-norm or cross-sample op; reference
 backend/app.py:80-103), so the batch dimension is split contiguously over the ranks and the
 forward needs no communication.  The only collective is one broadcast of the packed weights blob
-(cid_packed_weights_bytes(), ~30 MB: every kernel layout plus a reference-layout copy) from the rank that loaded the checkpoint:
-`torch.distributed.broadcast` on the "nccl" backend = RCCL over xGMI.  The reference has no
+(cid_packed_weights_bytes(), ~26 MB: every kernel layout plus a reference-layout copy) from the rank that loaded the checkpoint:
+`cid_broadcast_weights` = one `ncclBroadcast` (RCCL over xGMI) issued by libcid.so; torch.distributed carries only the 128-byte communicator id.  The reference has no
 distributed code; this is the build's own data-parallel driver.
 """
 from __future__ import annotations
@@ -28,24 +28,75 @@ def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return begin, begin + q + (1 if rank < r else 0)
 
 
+class WeightsComm:
+    """An RCCL communicator over the ranks of a torch.distributed group, created through the C ABI
+    (cid_comm_unique_id / cid_comm_init_rank, include/cid.h) so that the job's one collective — the broadcast of the
+    packed weights — is an `ncclBroadcast` issued by libcid.so itself.  torch.distributed is only the control channel
+    that carries the 128-byte unique id from rank `src` to the others."""
+
+    def __init__(self, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+        import ctypes
+
+        self._L = _lib.lib()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            _lib.check(None, self._L.cid_comm_unique_id(buf))
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        box = [ident.tolist()]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(box[0])
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(None, self._L.cid_comm_init_rank(ctypes.byref(self._comm), self.world, raw, self.rank))
+
+    def close(self) -> None:
+        if self._comm:
+            self._L.cid_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
     """Give every rank the weights of rank `src` with ONE broadcast of the packed blob.
 
-    GPU ranks (backend nccl = RCCL): the device blob is broadcast and attached in place, and the
-    nn.Parameters are refreshed from it.  CPU ranks (gloo, used by the CPU test-suite): the same
-    bytes travel as a host tensor."""
+    GPU ranks: `cid_broadcast_weights` — one in-place `ncclBroadcast` (RCCL over xGMI) of the device blob, issued from
+    the C ABI on the current stream; receivers attach it and refresh their nn.Parameters from it.  CPU ranks (gloo,
+    the CPU test-suite): the same bytes travel as a host tensor through torch.distributed."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     rank = dist.get_rank(group)
-    on_gpu = next(model.parameters()).device.type == "cuda"
-    nbytes = _lib.lib().cid_packed_weights_bytes()
-    if rank == src:
-        blob = model.pack_weights() if on_gpu else model.pack_weights_host()
-    else:
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=next(model.parameters()).device)
-    dist.broadcast(blob, src=src, group=group)
-    if rank != src:
-        model.adopt_packed_weights(blob, update_parameters=True)
+    dev = next(model.parameters()).device
+    on_gpu = dev.type == "cuda"
+    L = _lib.lib()
+    nbytes = L.cid_packed_weights_bytes()
+    if not on_gpu:
+        blob = model.pack_weights_host() if rank == src else torch.empty(nbytes, dtype=torch.uint8)
+        dist.broadcast(blob, src=src, group=group)
+        if rank != src:
+            model.adopt_packed_weights(blob, update_parameters=True)
+        return
+    comm = WeightsComm(dev, group)
+    try:
+        if rank == src:
+            blob = model.pack_weights()
+        else:
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(model._cid, L.cid_attach_weights(model._cid, blob.data_ptr()))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(model._cid, L.cid_broadcast_weights(model._cid, comm._comm, src, rank, stream))
+        if rank != src:
+            model.adopt_packed_weights(blob, update_parameters=True, host_is_current=True)
+        torch.cuda.current_stream(dev).synchronize()
+    finally:
+        comm.close()
 
 
 def denoise_sharded(model: DenoiseGenerator, make_shard, n_items: int, group: Optional[dist.ProcessGroup] = None):

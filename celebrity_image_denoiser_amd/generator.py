@@ -108,10 +108,11 @@ class DenoiseGenerator(nn.Module):
         self._blob, self._packed_sig = blob, sig
         return blob
 
-    def adopt_packed_weights(self, blob: torch.Tensor, update_parameters: bool = True) -> None:
+    def adopt_packed_weights(self, blob: torch.Tensor, update_parameters: bool = True, host_is_current: bool = False) -> None:
         """Use a packed device blob produced elsewhere (another rank's `pack_weights()`, received
         by RCCL broadcast).  With update_parameters the nn.Parameters are refreshed from it so
-        `state_dict()` agrees with what the kernels compute."""
+        `state_dict()` agrees with what the kernels compute.  host_is_current: the handle's host copy already
+        holds these bytes (cid_broadcast_weights refreshes it on receivers) — skip the device-to-host copy."""
         L = _lib.lib()
         if blob.dtype != torch.uint8 or blob.numel() != L.cid_packed_weights_bytes() or not blob.is_contiguous():
             raise ValueError("adopt_packed_weights: expected a contiguous uint8 tensor of cid_packed_weights_bytes()")
@@ -123,8 +124,9 @@ class DenoiseGenerator(nn.Module):
         else:
             update_parameters = True   # a host blob can only refresh the parameters; packing happens on .to('cuda')
         if update_parameters:
-            host = blob.cpu().numpy()
-            _lib.check(self._cid, L.cid_import_packed(self._cid, host.ctypes.data, host.nbytes))
+            if not host_is_current:
+                host = blob.cpu().numpy()
+                _lib.check(self._cid, L.cid_import_packed(self._cid, host.ctypes.data, host.nbytes))
             with torch.no_grad():
                 for key, p in self.named_parameters():
                     a = np.empty(tuple(p.shape), dtype=np.float32)
@@ -248,6 +250,24 @@ class DenoiseGenerator(nn.Module):
                                                                self._ws.data_ptr(), self._ws.numel(), stream, ms))
         return y, list(ms)
 
+
+    def stage_output(self, stage: str, n: int, h: int, w: int) -> torch.Tensor:
+        """Testing aid: the output of the reference module's submodule `stage` ("down1", "pool1", "down2", "pool2",
+        "bottleneck", "up2", "upconv2", "up1" — what a forward hook on it would record, app.py:81-96) as left in the
+        activation arena by the LAST forward of an [n,3,h,w] batch, returned as a fresh fp32 NCHW tensor.  Skip tensors
+        ("down1", "down2") cover only the top-left region the concat keeps (cid_stage_view, include/cid.h)."""
+        L = _lib.lib()
+        off, c, hs, ws, ps, coff = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = L.cid_stage_view(stage.encode(), n, h, w, ctypes.byref(off), ctypes.byref(c), ctypes.byref(hs), ctypes.byref(ws),
+                              ctypes.byref(ps), ctypes.byref(coff))
+        if rc != _lib.CID_OK:
+            raise KeyError(f"no stored stage {stage!r} for input [{n},3,{h},{w}] (cid_stage_view -> {rc})")
+        if self._ws is None:
+            raise RuntimeError("stage_output: no forward has run yet")
+        half = self.compute_dtype == "f16"
+        flat = self._ws[off.value:].view(torch.float16 if half else torch.float32)
+        view = flat[: n * hs.value * ws.value * ps.value].view(n, hs.value, ws.value, ps.value)[..., coff.value:coff.value + c.value]
+        return view.permute(0, 3, 1, 2).to(torch.float32).contiguous()
 
     @property
     def conv_algo(self) -> str:

@@ -176,6 +176,36 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
 
 /*
+ * Where the output of one of the reference module's stages lives in the workspace of an [N,3,H,W] forward (NHWC,
+ * fp32 — or half elements from the same base when the compute dtype is CID_DTYPE_F16).  `stage` is the attribute name of
+ * the reference module whose forward-hook output it is (backend/app.py:42-78): "down1", "pool1", "down2", "pool2",
+ * "bottleneck", "up2", "upconv2", "up1".  Element (n, y, x, c) of the stage is at
+ *     offset_bytes/elem_size + ((n*Hs + y)*Ws + x)*pixel_stride + channel_offset + c        for y < Hs, x < Ws, c < C.
+ * Skip tensors ("down1", "down2") are stored only over the region the concat keeps (top-left crop, app.py:90-92,97-99).
+ * "upconv1" (pre-tanh) is never stored: it is fused into the last kernel.  Testing aid for per-stage parity.
+ */
+int cid_stage_view(const char* stage, int N, int H, int W, size_t* offset_bytes, int* C, int* Hs, int* Ws,
+                   int* pixel_stride, int* channel_offset);
+
+/*
+ * Multi-GPU (one process per GPU, batch sharded): the job's ONE collective — an RCCL broadcast of the
+ * packed weights blob over xGMI from the rank that loaded the checkpoint — as a C entry point, so that a host which is
+ * not PyTorch can distribute weights too.  The reference has no distributed code; nothing here replaces a reference call.
+ *   comm   : an ncclComm_t (opaque pointer) spanning the ranks; create it with RCCL directly or with the three helpers
+ *            below (thin wrappers over ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy; the 128-byte unique id
+ *            travels from rank 0 to the others by whatever control channel the host has).
+ *   before : root has run cid_upload_weights; every other rank has attached an allocated, 256-byte aligned device buffer
+ *            of cid_packed_weights_bytes() with cid_attach_weights.
+ *   after  : every rank's attached blob holds root's weights (in place, on `stream`); non-root handles have also
+ *            refreshed their host copy (the call synchronises `stream` there), so cid_get_weight returns the new tensors.
+ * RCCL is resolved at run time from the process (dlopen of librccl.so.1): CID_ERR_STATE if it is not available.
+ */
+int cid_comm_unique_id(void* id128);
+int cid_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int cid_comm_destroy(void* comm);
+int cid_broadcast_weights(cid_handle_t h, void* comm, int root, int rank, void* stream);
+
+/*
  * Testing aid (no reference counterpart): fills the LDS of every CU with NaN on `stream`.  LDS is not cleared between
  * kernels, so a forward enqueued after it exposes any kernel that reads LDS words it has not written.
  */

@@ -14,9 +14,12 @@ Fixtures written (float32, numpy .npz):
   full_<wset>_128.npz        N=2 128x128: out only (input regenerated from synth; sha256 recorded)
   stats.json                 N=4 128x128 and N=1 256x256: per-stage sum / sumsq / min / max /
                              16 sampled elements, both weight sets; plus psnr figures
+  iter3_<wset>_32x32.npz     f2 row: N=3 32x32 through the ITERATED caller's own copy of the class
+                             (denoise_eavl_iter.py:8-60, lifted the same way) fed back 3 times like its loop
+                             (:93-96): input, the output of every iteration, the final uint8 view (:108-109)
 with <wset> in {default, hot}.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [--only iter3]      (--only: write just that family, leave the rest untouched)
 """
 import ast
 import hashlib
@@ -37,14 +40,50 @@ REF_APP = "/root/reference/backend/app.py"
 STAGES = ("down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1", "upconv1")
 
 
-def lift_reference_class():
-    with open(REF_APP, "r") as f:
-        tree = ast.parse(f.read(), REF_APP)
+REF_ITER = "/root/reference/backend/trainingcode/denoise_gan_code/denoise_eavl_iter.py"
+
+
+def lift_reference_class(path=REF_APP):
+    with open(path, "r") as f:
+        tree = ast.parse(f.read(), path)
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DenoiseGenerator"]
     assert len(cls) == 1
     ns = {"torch": torch, "nn": nn}
-    exec(compile(ast.Module(body=cls, type_ignores=[]), REF_APP, "exec"), ns)
+    exec(compile(ast.Module(body=cls, type_ignores=[]), path, "exec"), ns)
     return ns["DenoiseGenerator"]
+
+
+def write_iter3():
+    """f2 row.  The iterated caller (denoise_eavl_iter.py:62-114) builds ITS OWN copy of the class (:8-60), loads
+    checkpoint['generator'] (:68-69) and feeds the output back num_iterations=3 times (:93-96); the saved view is
+    current*0.5+0.5 through ToPILImage (:108-109; torchvision absent here: mul(255).byte(), written with torch ops)."""
+    cls = lift_reference_class(REF_ITER)
+    for wset in ("default", "hot"):
+        sd = synth.make_state_dict(wset)
+        model = cls()
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        model.eval()
+        x, _, _ = synth.make_batch(3, 32, 32, 80)
+        cur = torch.from_numpy(x)
+        outs = []
+        for _ in range(3):
+            with torch.no_grad():
+                cur = model(cur)
+            outs.append(cur.numpy().copy())
+        final_u8 = (cur * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).contiguous().numpy()
+        # how far the reference's own fp32 arithmetic drifts from the exact (float64) iteration: feeding the output back
+        # amplifies rounding differences, so the parity bound of iteration k is stated relative to this
+        m64 = cls().double()
+        m64.load_state_dict({k: torch.from_numpy(v).double() for k, v in sd.items()})
+        cur64, drift = torch.from_numpy(x).double(), []
+        for k in range(3):
+            with torch.no_grad():
+                cur64 = m64(cur64)
+            drift.append(float(np.abs(outs[k].astype(np.float64) - cur64.numpy()).max()))
+        np.savez_compressed(os.path.join(HERE, f"iter3_{wset}_32x32.npz"), x=x, iter1=outs[0], iter2=outs[1], iter3=outs[2],
+                            final_u8=final_u8, fp32_vs_fp64_maxabs=np.array(drift))
+        print(wset, "reference fp32 vs fp64 per iteration:", drift)
+    print("wrote iter3 fixtures to", HERE)
 
 
 def run(model, x):
@@ -77,6 +116,11 @@ def psnr(a, b):
 
 def main():
     torch.set_num_threads(8)
+    if "--only" in sys.argv:
+        what = sys.argv[sys.argv.index("--only") + 1]
+        {"iter3": write_iter3}[what]()
+        return
+    write_iter3()
     cls = lift_reference_class()
     stats = {"torch": torch.__version__, "reference": "backend/app.py:39-103 DenoiseGenerator (lifted by AST)"}
     for wset in ("default", "hot"):

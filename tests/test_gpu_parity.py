@@ -166,18 +166,104 @@ def test_state_dict_reload_repacks(models, weight_sets):
     assert np.array_equal(y1, _run(models["hot"], x)) and not np.array_equal(y0, y1)
 
 
-def test_iterated_denoise_and_host_roundtrip(models):
+STAGES = ("down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1")
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(
+    os.path.join(os.path.dirname(__file__), "golden", "tiny_*.npz"))))
+def test_every_stage_against_the_reference_hooks(models, golden_dir, name):
+    """Per-stage parity (only `out` was compared, so a regression could not be localised and compensating
+    errors in intermediates were invisible).  The tiny fixtures hold what forward hooks on the reference module's
+    submodules recorded; the same tensors are read back from the activation arena (cid_stage_view) after the forward.
+    Skip tensors are stored only over the top-left region the concat keeps (13x18 -> 12x16, 7x9 -> 4x8).
+    Stated tolerance: max|delta| <= 1e-5 * max(1, max|stage|)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = models[name.split("_")[1]]
+    n, _, h, w = g["x"].shape
+    y = _run(m, g["x"])
+    assert np.abs(y - g["out"]).max() <= TOL
+    # `upconv1` (pre-tanh) is fused into the last kernel and never stored: out = tanh(upconv1) ties it down
+    assert np.abs(y - np.tanh(g["upconv1"])).max() <= TOL
+    for st in STAGES:
+        got = m.stage_output(st, n, h, w).cpu().numpy()
+        ref = g[st][:, :, :got.shape[2], :got.shape[3]]
+        assert got.shape == ref.shape and got.shape[1] == g[st].shape[1], (st, got.shape, g[st].shape)
+        if st not in ("down1", "down2"):
+            assert got.shape == g[st].shape, (st, got.shape, g[st].shape)    # only skip tensors are cropped
+        tol = TOL * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= tol, (st, float(np.abs(got - ref).max()), tol)
+    with pytest.raises(KeyError):
+        m.stage_output("upconv1", n, h, w)
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_iterated_denoise_golden(models, golden_dir, wset):
+    """the iterated caller feeds the output back three times (denoise_eavl_iter.py:93-96).  Fixture:
+    the class of THAT file (lifted like app.py's) iterated on the CPU; it also records how far the reference's own fp32
+    run drifts from the float64 iteration (hot weights: 1.0e-6, 1.8e-6, 2.4e-6), so 1e-5 holds at every iteration."""
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import HostPipeline
+    from celebrity_image_denoiser_amd.api import to_unit_range
+
+    g = np.load(os.path.join(golden_dir, f"iter3_{wset}_32x32.npz"))
+    assert float(g["fp32_vs_fp64_maxabs"].max()) < TOL / 3
+    m = models[wset]
+    x = torch.from_numpy(g["x"])
+    for k in (1, 2, 3):
+        y = cid.denoise(m, x, iterations=k)
+        assert y.device.type == "cpu" and y.shape == x.shape
+        assert np.abs(y.numpy() - g[f"iter{k}"]).max() <= TOL, k
+    y3 = cid.denoise(m, x, iterations=3)
+    yp = HostPipeline(m)([g["x"]], iterations=3)[0]                  # upload / 3 forwards on the device / download
+    assert torch.equal(yp, y3)
+    assert torch.equal(cid.denoise(m, x, iterations=3, max_batch=2), y3)
+    # the saved view (:108-109): current*0.5+0.5 through ToPILImage (truncating)
+    u8 = to_unit_range(y3).mul(255).byte().permute(0, 2, 3, 1).numpy()
+    d = np.abs(u8.astype(np.int16) - g["final_u8"].astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+
+
+def test_load_checkpoint_by_path_and_run(tmp_path, golden_dir, weight_sets):
+    """SURVEY 8f row f3 on the GPU: cid.load(path) = torch-free reader -> load_state_dict -> pack -> forward, against the
+    golden output, for the trainer's checkpoint layout (training.py:359-376), the DataParallel 'module.'-prefixed keys the
+    reference loader strips (app.py:269-271), a bare state_dict, and the legacy (pre-zip) format."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    g = np.load(os.path.join(golden_dir, "tiny_hot_20x24.npz"))
+    sd = {k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}
+    extra = {"discriminator": {"w": torch.ones(3, 3)}, "g_optimizer": {"state": {}, "param_groups": [{"lr": 1e-4, "betas": (0.5, 0.999)}]},
+             "epoch": 499, "best_psnr": 30.5, "metric_history": {"psnr": [1.0]}}
+    files = {
+        "trainer.pth": dict(generator=sd, **extra),
+        "dataparallel.pth": dict(generator={"module." + k: v for k, v in sd.items()}, **extra),
+        "state_dict_key.pth": {"state_dict": sd},
+        "bare.pth": sd,
+    }
+    for fname, obj in files.items():
+        path = os.path.join(tmp_path, fname)
+        torch.save(obj, path)
+        m = cid.load(path, device="cuda:0", strict=True)
+        assert np.abs(_run(m, g["x"]) - g["out"]).max() <= TOL, fname
+        assert all(torch.equal(m.state_dict()[k].cpu(), v) for k, v in sd.items()), fname
+    legacy = os.path.join(tmp_path, "legacy.pth")
+    torch.save(files["dataparallel.pth"], legacy, _use_new_zipfile_serialization=False)
+    assert np.abs(_run(cid.load(legacy, device="cuda:0", strict=True), g["x"]) - g["out"]).max() <= TOL
+    # the reference's own loader entry point (app.py:257-274) on the build's module
+    m = cid.DenoiseGenerator().to("cuda:0")
+    cid.load_state_safely(m, os.path.join(tmp_path, "dataparallel.pth"))
+    assert not m.training and np.abs(_run(m, g["x"]) - g["out"]).max() <= TOL
+    with pytest.raises(RuntimeError):                                   # strict: a missing tensor is an error
+        torch.save({"generator": {k: v for k, v in sd.items() if k != "up1.bias"}}, os.path.join(tmp_path, "short.pth"))
+        cid.load(os.path.join(tmp_path, "short.pth"), device="cuda:0", strict=True)
+
+
+def test_host_roundtrip_and_batch_split(models):
     import celebrity_image_denoiser_amd as cid
 
     x = torch.from_numpy(synth.make_batch(3, 32, 32)[0])
-    y3 = cid.denoise(models["hot"], x, iterations=3)
-    assert y3.device.type == "cpu" and y3.shape == x.shape
-    z = x.to("cuda:0")
-    for _ in range(3):
-        z = models["hot"](z)
-    assert torch.equal(y3, z.cpu())
     y_split = cid.denoise(models["hot"], x, max_batch=2)
-    assert torch.equal(y_split, cid.denoise(models["hot"], x))
+    assert y_split.device.type == "cpu" and torch.equal(y_split, cid.denoise(models["hot"], x))
 
 
 def test_winograd_and_direct_agree(weight_sets):
@@ -415,6 +501,72 @@ def test_graphed_forward_matches_eager(models):
         assert torch.equal(fast8(t), m.forward_u8(t))
     with pytest.raises(RuntimeError):
         fast(torch.zeros((2, 3, 24, 40), device="cuda:0"))
+
+
+def test_graphed_forward_survives_arena_growth_and_new_weights(weight_sets):
+    """the captured graph holds raw pointers to the arena and the packed blob.  A later eager call with a
+    bigger batch replaces the model's arena, a parameter update its blob: the graph must keep working (private arena)
+    and follow the new weights (re-capture), not replay into freed memory or with stale weights."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import GraphedForward
+
+    m = cid.load(weight_sets["default"], device="cuda:0", strict=True)
+    x1 = torch.from_numpy(synth.make_batch(1, 24, 40, first_index=4100)[0]).to("cuda:0")
+    fast = GraphedForward(m, x1)
+    want = m(x1).clone()
+    big = torch.from_numpy(synth.make_batch(16, 96, 96, first_index=4200)[0]).to("cuda:0")
+    m(big)                                                   # grows (replaces) the model's own arena
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda:0") for _ in range(8)]   # reuse whatever was freed
+    torch.cuda.synchronize()
+    assert torch.equal(fast(x1), want)
+    del junk
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}, strict=True)
+    want_hot = m(x1).clone()
+    assert not torch.equal(want_hot, want)
+    assert torch.equal(fast(x1), want_hot)                   # noticed the new blob and re-captured
+
+
+def test_rccl_broadcast_through_the_c_abi(weight_sets):
+    """the one collective of the multi-GPU job is `cid_broadcast_weights` — ncclBroadcast issued by
+    libcid.so on a communicator made with cid_comm_* — here on the world this box has (one rank).  The receiver's
+    half (refresh of the host copy from the broadcast device blob) is driven by passing rank != root to the handle
+    of a second module attached to a copy of the blob."""
+    _need_gpu()
+    import ctypes
+
+    import torch.distributed as dist
+
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import _lib
+    from celebrity_image_denoiser_amd import dist as cdist
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        src = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+        x, _, _ = synth.make_batch(2, 32, 32, first_index=1400)
+        want = _run(src, x)
+        cdist.broadcast_weights(src, src=0)                 # comm init + ncclBroadcast (root side) + comm destroy
+        assert np.array_equal(_run(src, x), want)
+        comm = cdist.WeightsComm(torch.device("cuda:0"))
+        dst = cid.load(None, device="cuda:0")               # random init, like a rank that read no checkpoint
+        blob = src.pack_weights().clone()
+        L = _lib.lib()
+        _lib.check(dst._cid, L.cid_attach_weights(dst._cid, blob.data_ptr()))
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(dst._cid, L.cid_broadcast_weights(dst._cid, comm._comm, 0, 1, stream))   # receiver role
+        dst.adopt_packed_weights(blob, update_parameters=True, host_is_current=True)
+        comm.close()
+        assert all(torch.equal(dst.state_dict()[k].cpu(), torch.from_numpy(v)) for k, v in weight_sets["hot"].items())
+        assert np.array_equal(_run(dst, x), want)
+        h = ctypes.c_void_p()
+        L.cid_create(ctypes.byref(h))
+        assert L.cid_broadcast_weights(h, ctypes.c_void_p(8), 0, 0, None) == 4 and b"no device blob" in L.cid_last_error(h)
+        L.cid_destroy(h)
+    finally:
+        dist.destroy_process_group()
+
 
 
 def test_batch_past_2_31_elements_per_buffer(models):
