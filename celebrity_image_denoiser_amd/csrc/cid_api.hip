@@ -209,6 +209,7 @@ struct cid_handle_s {
     const float* dev_blob = nullptr;
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
+    int tail_algo = CID_TAIL_BANDS;    // last layer: row-band kernel (images up to 128 wide) or the tiled kernel everywhere
     int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: CID_ALGO_DIRECT (9-tap implicit GEMM) or Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
@@ -333,6 +334,12 @@ hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8, bool
     return hipGetLastError();
 }
 
+hipError_t launch_tail2(hipStream_t s, const Tail2Args& a, bool u8) {
+    if (u8) hipLaunchKernelGGL((k_conv_tail2<true>), dim3(a.groups_total), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_tail2<false>), dim3(a.groups_total), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int CIN, int COUT, int MODE>
 hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void* in, int Hin, int Win, int in_ps,
                          void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N) {
@@ -388,9 +395,10 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         a.in = in; a.w = blob + kBlob.w_off[0]; a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
-        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
+        tile_groups(a);
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
-        STEP(launch_head(s, a, 8 * g.per_xcd, in_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
+        STEP(launch_head(s, a, 8 * a.groups_per_xcd, in_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
     STEP((launch_layer<64, 64, 1>(h, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
@@ -410,13 +418,20 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     STEP((launch_layer<128, 64, 2>(h, s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // upconv1[0] + ReLU                                                                  app.py:75-76
     STEP((launch_layer<128, 64, 0>(h, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
-    {   // upconv1[2] + tanh, NHWC t4 -> NCHW out                                         app.py:77,103
+    // upconv1[2] + tanh, NHWC t4 -> NCHW out                                            app.py:77,103
+    if (h->dtype == CID_DTYPE_F32 && d.Wu1 <= T2_MAXW && h->tail_algo == CID_TAIL_BANDS) {   // row-band kernel: z once per pixel
+        Tail2Args a;
+        a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
+        a.N = N; a.H = d.Hu1; a.W = d.Wu1;
+        tail2_plan(a);
+        STEP(launch_tail2(s, a, out_fmt == CID_FMT_U8_NHWC));
+    } else {   // 8x32 tiles with halo: images wider than 128 pixels, and the fp16-storage path
         TailArgs a;
         a.in = B[T4]; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[11] : kBlob.w_off[11]); a.bias = blob + kBlob.b_off[11]; a.out = out;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
-        tail_groups(a);
+        tile_groups(a);
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
         STEP(launch_tail(s, a, 8 * a.groups_per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
     }
@@ -651,6 +666,17 @@ int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
     if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
+    return CID_OK;
+}
+int cid_set_tail_algo(cid_handle_t h, int algo) {
+    if (!h) return CID_ERR_INVALID;
+    if (algo != CID_TAIL_BANDS && algo != CID_TAIL_TILES) return fail(h, CID_ERR_INVALID, "cid_set_tail_algo: unknown algorithm");
+    h->tail_algo = algo;
+    return CID_OK;
+}
+int cid_get_tail_algo(cid_handle_t h, int* algo) {
+    if (!h || !algo) return CID_ERR_INVALID;
+    *algo = h->tail_algo;
     return CID_OK;
 }
 int cid_set_compute_dtype(cid_handle_t h, int dtype) {

@@ -472,13 +472,26 @@ struct HeadArgs {
     const float* bias;  // [64]
     void* out;          // NHWC [N,H,W,64]: fp32, or (OUT_F16) half for the fp16-storage path
     int N, H, W;
-    int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
+    int tiles_x, tiles_y, tiles_total;
+    int tiles_per_wg, groups_total, groups_per_xcd;   // a workgroup walks tiles_per_wg consecutive tiles (host: tile_groups)
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
+// Host: tiles per workgroup of the head and tail kernels — 4 once there are enough tiles to fill the chip several times
+// over, else 1 (small batches: more workgroups beat hidden latency).
+template <typename Args>
+inline void tile_groups(Args& a) {
+    a.tiles_per_wg = a.tiles_total >= 8192 ? 4 : 1;
+    a.groups_total = (a.tiles_total + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    a.groups_per_xcd = (a.groups_total + 7) / 8;
+}
 
 // IN_U8: the caller's image is uint8 HWC (what PIL hands the reference); ToTensor (/255) and Normalize(0.5,0.5)
 // (app.py:401-405) are applied on the fly, in fp32, with true divisions like torchvision: (u8/255 - 0.5)/0.5.
 // ABLATE (timing experiments only, tools/headtail_bench.hip; wrong results when non-zero): 1 no input loads, 2 no MFMAs, 4 no stores.
+//
+// A workgroup walks `a.tiles_per_wg` consecutive tiles.  The input elements of the NEXT tile are requested (into
+// registers) before the current tile's MFMAs and stores, so after the first tile no input latency is exposed
+// (tools/headtail_bench: removing the input loads altogether was worth 0.05 of this kernel's 0.23 ms).
 template <bool IN_U8, bool OUT_F16 = false, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #ifndef CID_EXPERIMENTS
@@ -488,45 +501,53 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     constexpr int STG16 = 16 * WS_STRIDE;                      // store staging per wave: 16 pixels x 64 channels
     __shared__ __attribute__((aligned(16))) float lds[3 * PLANE + 4 * STG16];   // input planes | store staging (21.7 KB)
     static_assert((3 * PLANE) % 4 == 0, "staging must stay 16-byte aligned");
-    int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, 1, mt, nb)) return;
-    int n, ty, tx;
-    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    int grp, nb;
+    if (!decode_block(a.groups_total, a.groups_per_xcd, 1, grp, nb)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
 
     // Input planes -> LDS.  All of a thread's loads are issued before the first is used (a load -> wait -> LDS write
-    // loop serialises four memory latencies per workgroup, which was most of this kernel's time): raw buffer loads
-    // over this image, out-of-image elements carry an out-of-range offset and read as zero.
+    // loop serialises four memory latencies per workgroup): raw buffer loads over the tile's image, out-of-image
+    // elements carry an out-of-range offset and read as zero.  Element s = it*256 + tid of the [3][LH][34] halo patch:
+    // its plane/row/column and its LDS index do not depend on the tile.
     constexpr int NS = 3 * LH * 34, NIT = (NS + THREADS - 1) / THREADS;
     const size_t img = (size_t)a.H * a.W * 3;   // elements per image in either input format
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-        IN_U8 ? (void*)(static_cast<const unsigned char*>(a.in) + (size_t)n * img) : (void*)(static_cast<const float*>(a.in) + (size_t)n * img),
-        (short)0, (int)(IN_U8 ? img : img * 4), 0x00020000);
-    unsigned goff[NIT];
-    int lidx[NIT];
+    int pc[NIT], phy[NIT], phx[NIT], lidx[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int s = it * THREADS + tid;
-        const int c = s / (LH * 34), rem = s - c * (LH * 34);
-        const int hy = rem / 34, hx = rem - hy * 34;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = s < NS && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        goff[it] = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((gy * a.W + gx) * 3 + c) : (unsigned)(((c * a.H + gy) * a.W + gx) * 4);
-        lidx[it] = s < NS ? c * PLANE + hy * LW + hx : -1;
+        pc[it] = s / (LH * 34);
+        const int rem = s - pc[it] * (LH * 34);
+        phy[it] = rem / 34; phx[it] = rem - phy[it] * 34;
+        lidx[it] = s < NS ? pc[it] * PLANE + phy[it] * LW + phx[it] : -1;
     }
     float staged[NIT];
+    auto request_tile = [&](int tile, int& tn, int& ty0, int& tx0) {
+        int ty, tx;
+        decode_tile(tile, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, tn, ty, tx);
+        ty0 = ty * TILE_H; tx0 = tx * TILE_W;
+        const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+            IN_U8 ? (void*)(static_cast<const unsigned char*>(a.in) + (size_t)tn * img) : (void*)(static_cast<const float*>(a.in) + (size_t)tn * img),
+            (short)0, (int)(IN_U8 ? img : img * 4), 0x00020000);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        if (ABLATE & 1) { staged[it] = (float)tid; continue; }
-        if (IN_U8) {
-            // zero padding applies to the NORMALISED tensor: a padded element is 0, not (0/255 - 0.5)/0.5
-            const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_in, goff[it], 0, 0);
-            staged[it] = goff[it] == 0x7ffffff0u ? 0.f : (t / 255.0f - 0.5f) / 0.5f;
-        } else {
-            staged[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff[it], 0, 0));
+        for (int it = 0; it < NIT; ++it) {
+            const int gy = ty0 - 1 + phy[it], gx = tx0 - 1 + phx[it];
+            const bool ok = lidx[it] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((gy * a.W + gx) * 3 + pc[it]) : (unsigned)(((pc[it] * a.H + gy) * a.W + gx) * 4);
+            if (ABLATE & 1) { staged[it] = (float)tid; continue; }
+            if (IN_U8) {
+                // zero padding applies to the NORMALISED tensor: a padded element is 0, not (0/255 - 0.5)/0.5
+                const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_in, goff, 0, 0);
+                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : 0.f;
+            } else {
+                staged[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+            }
         }
-    }
+    };
+
+    const int tile0 = grp * a.tiles_per_wg;
+    const int ntile = min(a.tiles_per_wg, a.tiles_total - tile0);   // >= 1 (decode_block), workgroup-uniform
+    int n, y0, x0;
+    request_tile(tile0, n, y0, x0);
     float bw[2][14], bias_v[2];
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
@@ -534,67 +555,73 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #pragma unroll
         for (int s = 0; s < 14; ++s) bw[ns][s] = a.w[(ns * 14 + s) * 64 + lane];
     }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-        if (lidx[it] >= 0) lds[lidx[it]] = staged[it];
-    __syncthreads();
-
     // One output row (32 pixels x 64 channels) at a time: 32 accumulator registers instead of 64 and a 16-pixel store
-    // slab per wave in its own LDS region, so that six workgroups fit a CU and one's stores, another's MFMAs and a
+    // slab per wave in its own LDS region, so that four workgroups fit a CU and one's stores, another's MFMAs and a
     // third's input latency overlap (tools/headtail_bench: 2 -> 3 -> 4 workgroups per CU = 0.305 -> 0.267 -> 0.235 ms).
     float* stg = lds + 3 * PLANE + wave * STG16;
     const int pbase = (2 * wave) * LW + i;
-    const bool full = y0 + TILE_H <= a.H && x0 + TILE_W <= a.W;
 #pragma unroll 1
-    for (int m = 0; m < 2; ++m) {   // not unrolled: hipcc would interleave the two rows and double the live accumulators
-        f32x16 acc[2];   // first written by the zero-C MFMAs of step 0
-        const int base_col = pbase + m * LW + h, base_row = pbase + m * LW + h * LW, base_plane = pbase + m * LW + h * PLANE;
+    for (int t = 0; t < ntile; ++t) {
 #pragma unroll
-        for (int s = 0; s < 14; ++s) {
-            const HeadStep hs = head_step(s);   // folds to constants after unrolling
-            const int o0 = (hs.addr / 9) * PLANE + ((hs.addr % 9) / 3) * LW + (hs.addr % 3);   // immediate
-            const float av = lds[(hs.dist == 0 ? base_col : hs.dist == 1 ? base_row : base_plane) + o0];
+        for (int it = 0; it < NIT; ++it)
+            if (lidx[it] >= 0) lds[lidx[it]] = staged[it];
+        __syncthreads();
+        int nn = n, ny0 = y0, nx0 = x0;
+        if (t + 1 < ntile) request_tile(tile0 + t + 1, nn, ny0, nx0);   // in flight under this tile's MFMAs and stores
+        const bool full = y0 + TILE_H <= a.H && x0 + TILE_W <= a.W;
+#pragma unroll 1
+        for (int m = 0; m < 2; ++m) {   // not unrolled: hipcc would interleave the two rows and double the live accumulators
+            f32x16 acc[2];   // first written by the zero-C MFMAs of step 0
+            const int base_col = pbase + m * LW + h, base_row = pbase + m * LW + h * LW, base_plane = pbase + m * LW + h * PLANE;
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) {
-                if ((ABLATE & 2) && s > 0) { acc[ns][s] += av * bw[ns][s]; continue; }
-                if (s == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], zero, 0, 0, 0);
+            for (int s = 0; s < 14; ++s) {
+                const HeadStep hs = head_step(s);   // folds to constants after unrolling
+                const int o0 = (hs.addr / 9) * PLANE + ((hs.addr % 9) / 3) * LW + (hs.addr % 3);   // immediate
+                const float av = lds[(hs.dist == 0 ? base_col : hs.dist == 1 ? base_row : base_plane) + o0];
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns) {
+                    if ((ABLATE & 2) && s > 0) { acc[ns][s] += av * bw[ns][s]; continue; }
+                    if (s == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], zero, 0, 0, 0);
+                    } else {
+                        acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], acc[ns], 0, 0, 0);
+                    }
+                }
+            }
+            if (ABLATE & 4) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[0][r] + acc[1][r];
+                if (sum == 123.456f) static_cast<float*>(a.out)[tid] = sum;
+                continue;
+            }
+            const int y = y0 + 2 * wave + m;
+            const bool rowok = y < a.H;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {   // accumulator registers 8q..8q+7 are pixels 16q..16q+15 of the row
+                auto val = [&](int ns, int k) { return fmaxf(acc[ns][8 * q + k] + bias_v[ns], 0.f); };
+                auto pix = [&](int k) { return (k & 3) + 8 * (k >> 2) + 4 * h; };
+                const int xq = x0 + 16 * q;
+                if (OUT_F16) {
+                    _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
+                    if (full)
+                        wide_store_h_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
+                    else
+                        wide_store_h<16>(stg, lane, val, pix,
+                                         [&](int px) -> _Float16* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
                 } else {
-                    acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[ns][s], acc[ns], 0, 0, 0);
+                    float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
+                    if (full)
+                        wide_store_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
+                    else
+                        wide_store<16>(stg, lane, val, pix,
+                                       [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
                 }
             }
         }
-        if (ABLATE & 4) {
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[0][r] + acc[1][r];
-            if (sum == 123.456f) static_cast<float*>(a.out)[tid] = sum;
-            continue;
-        }
-        const int y = y0 + 2 * wave + m;
-        const bool rowok = y < a.H;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {   // accumulator registers 8q..8q+7 are pixels 16q..16q+15 of the row
-            auto val = [&](int ns, int k) { return fmaxf(acc[ns][8 * q + k] + bias_v[ns], 0.f); };
-            auto pix = [&](int k) { return (k & 3) + 8 * (k >> 2) + 4 * h; };
-            const int xq = x0 + 16 * q;
-            if (OUT_F16) {
-                _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-                if (full)
-                    wide_store_h_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
-                else
-                    wide_store_h<16>(stg, lane, val, pix,
-                                     [&](int px) -> _Float16* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
-            } else {
-                float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-                if (full)
-                    wide_store_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
-                else
-                    wide_store<16>(stg, lane, val, pix,
-                                   [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
-            }
-        }
+        n = nn; y0 = ny0; x0 = nx0;
+        if (t + 1 < ntile) __syncthreads();   // every wave is done reading the planes before the next tile overwrites them
     }
 }
 
@@ -616,13 +643,6 @@ struct TailArgs {
     int tiles_per_wg, groups_total, groups_per_xcd;   // a workgroup walks tiles_per_wg consecutive tiles (host: tail_groups)
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
-// Host: tiles per workgroup — 4 once there are enough tiles to fill the chip several times over, else 1.
-inline void tail_groups(TailArgs& a) {
-    a.tiles_per_wg = a.tiles_total >= 8192 ? 4 : 1;
-    a.groups_total = (a.tiles_total + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    a.groups_per_xcd = (a.groups_total + 7) / 8;
-}
-
 // OUT_U8: the reference's view transform and PIL conversion folded in: y*0.5+0.5, clamp to [0,1] (app.py:435),
 // then ToPILImage's mul(255).byte() — truncation, not rounding (app.py:471-472; denoisegan_eval.py:97-98).
 // ABLATE (timing experiments only): 1 no input loads, 2 no MFMAs, 8 no gather/tanh/store epilogue.
@@ -794,6 +814,244 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv_tail(const TailArgs a) {
             if (sum == 123.456f) static_cast<float*>(a.out)[tid] = sum;
         }
         n = nn; y0 = ny0; x0 = nx0;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Tail, second decomposition (the default for images up to 128 pixels wide): a workgroup owns a BAND of rows of one
+// image and slides down it, one row per step.
+//
+//   z[p][3*tap + co] = sum_ci x[p][ci] * W[co][ci][tap]        once per PIXEL p  (k_conv_tail: once per pixel of every
+//                                                               tile's halo, 340 per 256 outputs)
+//   out[y][x][co]    = bias[co] + sum_{ty,tx} z[(y+ty-1, x+tx-1)][3*(3*ty+tx) + co],   then tanh
+//
+//   * a z row (<= 128 pixels) = 4 MFMA M-tiles, one per wave: [32 pixels x 64 ci] x [64 x 32 (27 used)], 32 MFMAs;
+//   * every wave is self-sufficient for x: it requests, TWO ROWS ahead and straight into registers, exactly the pixels of
+//     its own M-tile (half-row chunks of 32 pixels x 32 channels = 4 KiB, 16 VGPRs per chunk, four chunks in flight),
+//     transposes them through a wave-private 4 KiB LDS buffer (16-byte ds_write, ds_read_b128 A fragments) and runs its
+//     MFMAs — no workgroup barrier stands between a load and its use, so one wave's memory latency never stalls
+//     another.  The data in flight lives in the register file (512 KiB per CU), not in LDS: three workgroups fit a CU
+//     (44 KiB of LDS each) with 192 KiB of loads in flight per CU.  hipcc counts the waits itself (plain loads/stores);
+//   * the 16-byte quads of a pixel are stored XOR-swizzled — physical quad = logical quad ^ ((pixel >> 1) & 7) — which
+//     makes every ds_read_b128 of an A fragment conflict-free without padding: within each of the instruction's four
+//     16-lane service groups the 16 pixels then cover all 16 four-bank columns;
+//   * a z row goes to LDS once ([130 entries][27], entry e = column e-1; entries 0 and 129 are the zero padding; two
+//     slots, alternating) and is gathered once: it contributes to output rows zr-1 (ty=2), zr (ty=1) and zr+1 (ty=0),
+//     whose partial sums live in registers — lane (i, h) of wave w owns pixel 32w+i; h=0 sums the taps (ty0: tx0,1,2),
+//     (ty1: tx0,1), h=1 the taps (ty1: tx2), (ty2: tx0,1,2); the halves meet through one v_permlane32_swap per channel
+//     when a row completes;
+//   * ONE barrier per row (between a z row's write and its gather: neighbouring pixels belong to other waves);
+//   * straight-line row loop: rows outside the image are read through an empty buffer descriptor (zeros, no traffic) and
+//     rows outside the band are "stored" at an out-of-range offset, so no branch splits hipcc's wait counting.
+struct Tail2Args {
+    const float* in;    // NHWC [N,H,W,64] fp32
+    const float* w;     // packed as for k_conv_tail: [2 chunk][4 group][64 lanes][4]
+    const float* bias;  // [3]
+    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
+    int N, H, W;
+    int band_rows, bands_per_image, groups_total;   // host: tail2_plan
+    unsigned rcp_bands;                              // ceil(2^32 / bands_per_image)
+};
+constexpr int T2_MAXW = 128;
+// Host: rows per band — as tall as possible (every band re-reads two halo rows) while the launch still has three
+// workgroups for every CU.
+inline void tail2_plan(Tail2Args& a, int rows = 0) {
+    int r = 64;
+    while (r > 8 && (long long)a.N * ((a.H + r - 1) / r) < 768) r >>= 1;
+    if (rows > 0) r = rows;
+    a.band_rows = r;
+    a.bands_per_image = (a.H + r - 1) / r;
+    a.groups_total = a.N * a.bands_per_image;
+    a.rcp_bands = tile_rcp((unsigned)a.bands_per_image);
+}
+
+// ABLATE (timing experiments only): 1 no input loads, 2 no MFMAs, 4 no gather/tanh/stores.
+template <bool OUT_U8, int ABLATE = 0>
+__global__ void __launch_bounds__(THREADS, 3) k_conv_tail2(const Tail2Args a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
+    constexpr int WAVE_SLOTS = 32 * 8;                     // wave-private x buffer: 32 pixels x 8 quads of 16 B = 4 KiB
+    constexpr int NPW = 4;                                 // pieces (16 B per lane, 8 pixels) per wave and chunk
+    constexpr int ZE = T2_MAXW + 2, ZC = 27;               // z row: 130 entries x 27 columns
+    constexpr int ZROW = ZE * ZC + 2;                      // floats per z slot (16-byte multiple)
+    static_assert((ZROW % 4) == 0, "layout");
+    __shared__ f32x4 lds[4 * WAVE_SLOTS + (2 * ZROW + 4) / 4];   // 16,384 + 28,096 + 16 B
+    float* const zl = reinterpret_cast<float*>(lds + 4 * WAVE_SLOTS);
+    constexpr int ZERO_AT = 2 * ZROW;                      // floats ZERO_AT .. +2 stay zero (the padded taps read them)
+
+    const int grp = blockIdx.x;
+    if (grp >= a.groups_total) return;
+    const unsigned ug = (unsigned)__builtin_amdgcn_readfirstlane(grp);
+    const int n = (int)(a.rcp_bands ? __umulhi(ug, a.rcp_bands) : ug);
+    const int band = grp - n * a.bands_per_image;
+    const int r0 = band * a.band_rows, r1 = min(r0 + a.band_rows, a.H);   // output rows [r0, r1)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+
+    // ---- weights (B operand) and bias: once per workgroup ----
+    f32x4 wb[2][4];
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wb[ck][g] = reinterpret_cast<const f32x4*>(a.w)[(ck * 4 + g) * 64 + lane];
+    float bias_v[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bias_v[co] = a.bias[co];
+
+    // ---- this wave's input pieces: piece m covers pixels 32*wave + 8*m .. +8; lane -> (pixel, logical quad lane & 7) ----
+    // One buffer descriptor per ROW (num_records = the row's bytes, or 0 for a row outside the image): pixels past the row
+    // end and whole zero rows are out of range and read as zeros; piece m is piece 0's offset + m * 2 KiB, and its LDS slot
+    // is piece 0's + 64 m (8 pixels further on).
+    const float* inb = a.in + (size_t)n * a.H * a.W * 64;
+    const int pl0 = lane >> 3, q0 = lane & 7;              // pixel within the wave's 32, quad
+    const unsigned voff0 = (unsigned)((32 * wave + pl0) * 256 + q0 * 16);
+    f32x4* const xw = lds + wave * WAVE_SLOTS;             // this wave's buffer
+    int wslot[NPW];
+#pragma unroll
+    for (int m = 0; m < NPW; ++m) { const int pl = 8 * m + pl0; wslot[m] = pl * 8 + (q0 ^ ((pl >> 1) & 7)); }
+    const int zr_first = r0 - 1, zr_last = r1;             // z rows needed: [r0-1, r1]
+    f32x4 stage[4][NPW];                                   // chunk (row zr_first + k, half) lives in stage[2*(k&1) + half]
+    auto request = [&](auto slot_tag, int zr, int half) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        if (ABLATE & 1) return;
+        const bool ok = zr >= 0 && zr < a.H && zr <= zr_last;
+        const int zc = ok ? zr : 0;
+        const __amdgpu_buffer_rsrc_t rsrc_row = __builtin_amdgcn_make_buffer_rsrc((void*)(inb + (size_t)zc * a.W * 64), (short)0, ok ? a.W * 256 : 0, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < NPW; ++m)
+            stage[SLOT][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_row, voff0 + m * 2048, half * 128, 0));
+    };
+    auto to_lds = [&](auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        if (ABLATE & 1) return;
+#pragma unroll
+        for (int m = 0; m < NPW; ++m) xw[wslot[m]] = stage[SLOT][m];
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+    request(S0{}, zr_first, 0);
+    request(S1{}, zr_first, 1);
+    request(S2{}, zr_first + 1, 0);
+    request(S3{}, zr_first + 1, 1);
+    // The weights were requested BEFORE the four chunks; using them here makes hipcc wait for them now (they are the oldest
+    // loads in flight: the chunks stay in flight).  Without this their wait sits in front of the loop's first MFMAs, where
+    // its count (set by the first iteration) would force all but seven of the loads in flight to land in EVERY iteration.
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(wb[ck][g]));
+
+    // ---- output addressing: two buffer stores per row; lanes (and rows) with nothing to store carry an out-of-range offset ----
+    const int px = 32 * wave + i;                          // this lane's pixel (output column)
+    const size_t plane = (size_t)a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+        OUT_U8 ? (void*)(static_cast<unsigned char*>(a.out) + (size_t)n * plane * 3) : (void*)(static_cast<float*>(a.out) + (size_t)n * plane * 3),
+        (short)0, (int)(OUT_U8 ? plane * 3 : plane * 12), 0x00020000);
+    // store 1: channel h of pixel px; store 2: channel 2 (h = 0 lanes only)
+    const unsigned ooff1 = px < a.W ? (OUT_U8 ? (unsigned)(px * 3 + h) : (unsigned)((h * plane + px) * 4)) : 0x7ffffff0u;
+    const unsigned ooff2 = (px < a.W && h == 0) ? (OUT_U8 ? (unsigned)(px * 3 + 2) : (unsigned)((2 * plane + px) * 4)) : 0x7ffffff0u;
+
+    // ---- A fragments: logical quad 2g+h of pixel i of the wave's buffer, swizzled: slot = 8 i + ((2g + h) ^ swz) = (8 i + (h ^ swz)) ^ 2g ----
+    const int aslot0 = i * 8 + (h ^ ((i >> 1) & 7));
+
+    // ---- gather addresses (floats into a z slot): group U completes a row, group V is carried to the next step ----
+    //   h=0: U = ty1 (tx0, tx1, zero)   V = ty0 (tx0, tx1, tx2)        h=1: U = ty2 (tx0, tx1, tx2)   V = ty1 (tx2, zero, zero)
+    // The padded taps point at the zero triple: their address must not move with the slot, hence two bases per group.
+    auto tap_at = [&](int ty, int tx) { return (px + tx) * ZC + (3 * ty + tx) * 3; };
+    const int ua0 = h ? tap_at(2, 0) : tap_at(1, 0), ua1 = h ? tap_at(2, 1) : tap_at(1, 1);
+    const int va0 = h ? tap_at(1, 2) : tap_at(0, 0);
+    const int ua2[2] = {h ? tap_at(2, 2) : ZERO_AT, h ? tap_at(2, 2) + ZROW : ZERO_AT};
+    const int va1[2] = {h ? ZERO_AT : tap_at(0, 1), h ? ZERO_AT : tap_at(0, 1) + ZROW};
+    const int va2[2] = {h ? ZERO_AT : tap_at(0, 2), h ? ZERO_AT : tap_at(0, 2) + ZROW};
+
+    // zero padding of both z slots (entries 0 and 129) and the zero triple: written once, never overwritten
+    if (tid < ZC) { zl[tid] = 0.f; zl[(ZE - 1) * ZC + tid] = 0.f; zl[ZROW + tid] = 0.f; zl[ZROW + (ZE - 1) * ZC + tid] = 0.f; }
+    if (tid < 4) zl[ZERO_AT + tid] = 0.f;
+
+    f32x16 acc;
+    float carry[3] = {0.f, 0.f, 0.f}, tprev[3] = {0.f, 0.f, 0.f};
+    auto mfma_chunk = [&](auto first_tag, auto half_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int HALF = decltype(half_tag)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int sl = aslot0 ^ (2 * g);
+            if (g) asm volatile("" : "+v"(sl));            // keep the xor at its use: hoisted out of the row loop it costs three VGPRs (and spilled)
+            const f32x4 av = xw[sl];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ABLATE & 2) { acc[4 * g + e] = av[e] * wb[HALF][g][e]; continue; }
+                if (FIRST && g == 0 && e == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[HALF][g][e], zero, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[HALF][g][e], acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    // gather z row `zr` (slot Z) into the partial sums; emit output row zr-1 (dropped by the range check outside the band)
+    auto gather_emit = [&](auto z_tag, int zr) {
+        constexpr int Z = decltype(z_tag)::value;
+        if (ABLATE & 4) return;
+        const float* zs = zl + Z * ZROW;
+        float tot[3];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            const float u = (zs[ua0 + co] + zs[ua1 + co]) + zl[ua2[Z] + co];
+            const float v = (zs[va0 + co] + zl[va1[Z] + co]) + zl[va2[Z] + co];
+            const float t = carry[co] + u;                 // h=0: a(zr) = ty0(zr-1) + ty1'(zr);  h=1: d(zr-1) = ty1''(zr-1) + ty2(zr)
+            carry[co] = v;
+            const float wv = h ? t : tprev[co];            // h=0: a(zr-1), h=1: d(zr-1): the two parts of output row zr-1
+            tprev[co] = t;
+            // v_permlane32_swap x, y exchanges x[32..63] with y[0..31]: with y a copy of x the results are {lo, lo} and
+            // {hi, hi}, whose sum is a + d in both halves.  Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2)
+            // turned the sum of the builtin's two results into 2 x the first one.  s_nop: VALU write -> permlane read hazard.
+            float wx = wv, wy = wv;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(wx), "+v"(wy));
+            tot[co] = (wx + wy) + bias_v[co];
+        }
+        const int y = zr - 1;
+        const bool emit = y >= r0 && y < r1;               // workgroup-uniform
+        const float v1 = tanhf(h ? tot[1] : tot[0]), v2 = tanhf(tot[2]);
+        if (OUT_U8) {
+            const int so = emit ? y * a.W * 3 : 0;
+            const float q1 = fminf(fmaxf(v1 * 0.5f + 0.5f, 0.f), 1.f), q2 = fminf(fmaxf(v2 * 0.5f + 0.5f, 0.f), 1.f);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(q1 * 255.0f), rsrc_out, emit ? ooff1 : 0x7ffffff0u, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(q2 * 255.0f), rsrc_out, emit ? ooff2 : 0x7ffffff0u, so, 0);
+        } else {
+            const int so = emit ? y * a.W * 4 : 0;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rsrc_out, emit ? ooff1 : 0x7ffffff0u, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rsrc_out, emit ? ooff2 : 0x7ffffff0u, so, 0);
+        }
+    };
+
+    // One row step.  P = parity of the step: its chunks sit in stage[2P], stage[2P+1] and its z row goes to slot P; a stage
+    // slot that has gone to LDS is re-requested at once for the row two steps down.  Within a wave LDS operations execute in
+    // order, so the wave-private buffer needs no barrier: write half 0, read its fragments, MFMAs, write half 1, read, MFMAs.
+    auto step = [&](auto parity_tag, int zr) {
+        constexpr int P = decltype(parity_tag)::value;
+        using SA = std::integral_constant<int, 2 * P>; using SB = std::integral_constant<int, 2 * P + 1>;
+        to_lds(SA{});
+        request(SA{}, zr + 2, 0);
+        mfma_chunk(std::true_type{}, std::integral_constant<int, 0>{});
+        to_lds(SB{});
+        request(SB{}, zr + 2, 1);
+        mfma_chunk(std::false_type{}, std::integral_constant<int, 1>{});
+        if (i < ZC) {                                      // lane holds column i = 3*tap + co of pixels (r&3) + 8*(r>>2) + 4*h
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zl[P * ZROW + (32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h + 1) * ZC + i] = acc[r];
+        }
+        __syncthreads();                                   // z row zr is complete; every wave is past its gather of row zr-1
+        gather_emit(parity_tag, zr);
+    };
+    for (int zr = zr_first; zr <= zr_last; zr += 2) {      // an odd count of rows runs one extra step on an empty row (nothing stored)
+        step(std::integral_constant<int, 0>{}, zr);
+        step(std::integral_constant<int, 1>{}, zr + 1);
     }
 }
 

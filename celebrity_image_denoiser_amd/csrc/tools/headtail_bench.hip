@@ -12,13 +12,14 @@ using namespace cid;
 struct Variant { std::string name; std::function<void(hipStream_t)> run; };
 
 template <int ABLATE>
-static Variant head(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int extra_lds) {
+static Variant head(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int extra_lds, int tpw = 0) {
     HeadArgs a{};
     a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
-    a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    a.tiles_total = N * a.tiles_x * a.tiles_y; tile_groups(a);
+    if (tpw > 0) { a.tiles_per_wg = tpw; a.groups_total = (a.tiles_total + tpw - 1) / tpw; a.groups_per_xcd = (a.groups_total + 7) / 8; }
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    const int grid = 8 * a.tiles_per_xcd;
+    const int grid = 8 * a.groups_per_xcd;
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_head<false, false, ABLATE>), dim3(grid), dim3(THREADS), extra_lds, s, a); }};
 }
 template <int ABLATE>
@@ -26,11 +27,20 @@ static Variant tail(const char* name, int N, int H, int W, float* in, float* w, 
     TailArgs a{};
     a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
-    a.tiles_total = N * a.tiles_x * a.tiles_y; tail_groups(a);
+    a.tiles_total = N * a.tiles_x * a.tiles_y; tile_groups(a);
     if (tpw > 0) { a.tiles_per_wg = tpw; a.groups_total = (a.tiles_total + tpw - 1) / tpw; a.groups_per_xcd = (a.groups_total + 7) / 8; }
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
     const int grid = 8 * a.groups_per_xcd;
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_tail<false, false, ABLATE>), dim3(grid), dim3(THREADS), extra_lds, s, a); }};
+}
+
+template <int ABLATE>
+static Variant tail2(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int rows = 0) {
+    Tail2Args a{};
+    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
+    tail2_plan(a, rows);
+    const int grid = a.groups_total;
+    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_tail2<false, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }};
 }
 
 int main(int argc, char** argv) {
@@ -42,7 +52,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&w, 1 << 16)); CK(hipMemset(w, 0, 1 << 16));
     CK(hipMalloc(&b, 1 << 10)); CK(hipMemset(b, 0, 1 << 10));
     std::vector<Variant> v;
-    v.push_back(head<0>("head base (4 WG/CU)", N, H, W, img, w, b, act, 0));
+    v.push_back(head<0>("head base (4 WG/CU, 4 tiles/WG)", N, H, W, img, w, b, act, 0));
+    v.push_back(head<0>("head 1 tile/WG", N, H, W, img, w, b, act, 0, 1));
+    v.push_back(head<0>("head 2 tiles/WG", N, H, W, img, w, b, act, 0, 2));
+    v.push_back(head<0>("head 8 tiles/WG", N, H, W, img, w, b, act, 0, 8));
+    v.push_back(head<0>("head 16 tiles/WG", N, H, W, img, w, b, act, 0, 16));
     v.push_back(head<0>("head 3 WG/CU", N, H, W, img, w, b, act, 12 * 1024));
     v.push_back(head<0>("head 2 WG/CU", N, H, W, img, w, b, act, 36 * 1024));
     v.push_back(head<1>("head no-input-loads", N, H, W, img, w, b, act, 0));
@@ -59,6 +73,15 @@ int main(int argc, char** argv) {
     v.push_back(tail<2>("tail no-mfma", N, H, W, act, w, b, img, 0));
     v.push_back(tail<8>("tail no-epilogue", N, H, W, act, w, b, img, 0));
     v.push_back(tail<10>("tail loads only", N, H, W, act, w, b, img, 0));
+    v.push_back(tail2<0>("tail2 base (default bands)", N, H, W, act, w, b, img));
+    v.push_back(tail2<0>("tail2 64-row bands", N, H, W, act, w, b, img, 64));
+    v.push_back(tail2<0>("tail2 32-row bands", N, H, W, act, w, b, img, 32));
+    v.push_back(tail2<0>("tail2 16-row bands", N, H, W, act, w, b, img, 16));
+    v.push_back(tail2<0>("tail2 128-row bands", N, H, W, act, w, b, img, 128));
+    v.push_back(tail2<1>("tail2 no-dma", N, H, W, act, w, b, img));
+    v.push_back(tail2<2>("tail2 no-mfma", N, H, W, act, w, b, img));
+    v.push_back(tail2<4>("tail2 no-gather", N, H, W, act, w, b, img));
+    v.push_back(tail2<6>("tail2 dma only", N, H, W, act, w, b, img));
     std::vector<std::vector<float>> ms(v.size());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& x : v) x.run(s);

@@ -285,6 +285,21 @@ class DenoiseGenerator(nn.Module):
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
     @property
+    def tail_algo(self) -> str:
+        """"bands" (default: row-band kernel for the last layer, images up to 128 pixels wide) or "tiles" (the tiled kernel
+        everywhere).  Same function; both go through the parity tests."""
+        a = ctypes.c_int()
+        _lib.check(self._cid, _lib.lib().cid_get_tail_algo(self._cid, ctypes.byref(a)))
+        return "tiles" if a.value == _lib.CID_TAIL_TILES else "bands"
+
+    @tail_algo.setter
+    def tail_algo(self, name: str) -> None:
+        algo = {"bands": _lib.CID_TAIL_BANDS, "tiles": _lib.CID_TAIL_TILES}.get(name)
+        if algo is None:
+            raise ValueError("tail_algo must be 'bands' or 'tiles'")
+        _lib.check(self._cid, _lib.lib().cid_set_tail_algo(self._cid, algo))
+
+    @property
     def compute_dtype(self) -> str:
         """"f32" (default: the reference's arithmetic) or "f16" (half storage between the first and last kernel,
         fp16 MFMA with fp32 accumulators; BASELINE configs[4]).  Inputs/outputs keep their formats."""

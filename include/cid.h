@@ -171,6 +171,15 @@ int cid_set_compute_dtype(cid_handle_t h, int dtype);
 int cid_get_compute_dtype(cid_handle_t h, int* dtype);
 int cid_set_conv_algo(cid_handle_t h, int algo);
 int cid_get_conv_algo(cid_handle_t h, int* algo);
+/*
+ * Decomposition of the last layer (upconv1[2] + tanh, backend/app.py:77,103) on the fp32 path; same function either way:
+ *   CID_TAIL_BANDS  a workgroup slides down a band of rows, the 64 -> 27 (tap x channel) product is computed once per
+ *                   pixel (default; images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
+ *   CID_TAIL_TILES  8x32-pixel tiles, the product is computed over each tile's halo (round 1's kernel)
+ */
+enum { CID_TAIL_BANDS = 0, CID_TAIL_TILES = 1 };
+int cid_set_tail_algo(cid_handle_t h, int algo);
+int cid_get_tail_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);

@@ -30,7 +30,8 @@ def _need_gpu():
 @pytest.fixture(scope="module", params=["winograd64", "direct"])
 def models(request, weight_sets):
     """Both algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(2x2,3x3)
-    (the default) and the 9-tap implicit GEMM."""
+    (the default) and the 9-tap implicit GEMM; and with them both decompositions of the last layer: the row-band kernel
+    (default) and the tiled kernel (which also serves images wider than 128 pixels under the default)."""
     _need_gpu()
     import celebrity_image_denoiser_amd as cid
 
@@ -38,7 +39,8 @@ def models(request, weight_sets):
     for k, v in weight_sets.items():
         m = cid.load(v, device="cuda:0", strict=True)
         m.conv_algo = request.param
-        assert m.conv_algo == request.param
+        m.tail_algo = "tiles" if request.param == "direct" else "bands"
+        assert m.conv_algo == request.param and m.tail_algo == ("tiles" if request.param == "direct" else "bands")
         out[k] = m
     return out
 
@@ -159,7 +161,7 @@ def test_state_dict_reload_repacks(models, weight_sets):
 
     x, _, _ = synth.make_batch(1, 16, 16)
     m = cid.load(weight_sets["default"], device="cuda:0")
-    m.conv_algo = models["hot"].conv_algo
+    m.conv_algo, m.tail_algo = models["hot"].conv_algo, models["hot"].tail_algo
     y0 = _run(m, x)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}, strict=True)
     y1 = _run(m, x)
@@ -371,13 +373,14 @@ def test_hip_graph_capture_and_replay(weight_sets):
     assert torch.equal(static_y, m(x2)) and not torch.equal(m(x1), m(x2))
 
 
-@pytest.mark.parametrize("wset,tol", [("default", 5e-4), ("hot", 2e-2)])
+@pytest.mark.parametrize("wset,tol", [("default", 5e-4), ("hot", 5e-3)])
 def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
     """BASELINE configs[4]: half storage + fp16 MFMA (fp32 accumulators) against the fp32 golden output.
     A separate numerical contract: every stored activation and weight is rounded to half (2^-11 relative), so the
-    stated tolerance is relative to the activation scale: max|delta| <= 5e-4 at PyTorch-default weight scale
-    (outputs within +-0.07; BASELINE.md's 5e-3 bound with room to spare), <= 2e-2 on the He-gain weights
-    (activations up to 5, tanh to +-0.98); PSNR delta vs the fp32 reference is reported by the assertion message."""
+    stated tolerance is BASELINE.md section 4 / SURVEY 8(d)'s for this config: max|delta| <= 5e-3 — held on the He-gain
+    ("hot") weights (activations up to 5, tanh to +-0.98; measured 2.7e-3, bench.py configs[4].max_abs_err_hot_weights)
+    and with a factor 10 to spare at PyTorch-default weight scale (<= 5e-4; measured 4.4e-5).  PSNR delta vs the fp32
+    reference is reported by the assertion message."""
     _need_gpu()
     import celebrity_image_denoiser_amd as cid
     from celebrity_image_denoiser_amd import psnr
@@ -397,7 +400,7 @@ def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
     assert np.abs(_run(m, gt["x"]) - gt["out"]).max() <= tol
     gu = np.load(os.path.join(golden_dir, f"u8_{wset}_32x40.npz"))
     yu = m.forward_u8(torch.from_numpy(gu["noisy_u8"]).to("cuda:0")).cpu().numpy().astype(np.int16)
-    assert np.abs(yu - gu["out_u8"].astype(np.int16)).max() <= (1 if wset == "default" else 4)
+    assert np.abs(yu - gu["out_u8"].astype(np.int16)).max() <= (1 if wset == "default" else 2)
     m.compute_dtype = "f32"
     assert np.abs(_run(m, x) - g["out"]).max() <= TOL
 
