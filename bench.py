@@ -87,9 +87,6 @@ def cpu_baseline(sd, budget_s: float = 15.0):
     return out
 
 
-WINOGRAD_EXECUTED = 16.0 / 36.0   # F(2x2,3x3): 16 multiplies per 2x2 outputs and (ci,co) where the direct algorithm has 36
-
-
 def layer_report(table, launch_ms, nfw, n_img, S, f16):
     """Per-launch rates and roofline fractions from HIP-event timings.
 
@@ -100,12 +97,11 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
     the algorithmic rate is reported beside it as `tflops_algorithmic`."""
     peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
     layers, exec_total = [], 0.0
-    for li, ((name, kern, flops, nbytes), ms_sum) in enumerate(zip(table, launch_ms)):
+    for li, ((name, kern, flops, nbytes, executed), ms_sum) in enumerate(zip(table, launch_ms)):
         if f16:   # half activations and weights; the caller-side fp32 tensors of the first/last launch stay fp32
             io = 4.0 * n_img * 3 * S * S
             nbytes = (nbytes - io) / 2 + io if li in (0, len(table) - 1) else nbytes / 2
         ms = ms_sum / max(nfw, 1)
-        executed = flops * (WINOGRAD_EXECUTED if "wino" in kern else 1.0)
         exec_total += executed
         t_mfma, t_hbm = executed / (peak_tf * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
@@ -133,7 +129,7 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
     else:
         roof = {"bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["frac"], "traffic": traffic}
     roof.update({"kernel": d["kernel"], "layer": d["layer"], "avg_launch_ms": d["ms"], "launches_timed": nfw,
-                 "flops_per_launch": table[dom][2], "executed_flops_per_launch": table[dom][2] * (WINOGRAD_EXECUTED if "wino" in d["kernel"] else 1.0),
+                 "flops_per_launch": table[dom][2], "executed_flops_per_launch": table[dom][4],
                  "bytes_per_launch": table[dom][3]})
     return layers, roof, exec_total
 

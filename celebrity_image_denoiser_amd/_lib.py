@@ -13,7 +13,7 @@ CID_NUM_LAUNCHES = 12
 CID_ALGO_DIRECT, CID_ALGO_WINOGRAD64 = 0, 2
 CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
 CID_DTYPE_F32, CID_DTYPE_F16 = 0, 1
-CID_TAIL_BANDS, CID_TAIL_TILES = 0, 1
+CID_TAIL_FUSED, CID_TAIL_BANDS, CID_TAIL_TILES = 0, 1, 2
 
 # every symbol include/cid.h declares: (restype, argtypes)
 _c = ctypes
@@ -50,6 +50,7 @@ SYMBOLS = {
     "cid_debug_poison_lds": (_c.c_int, [_c.c_void_p]),
     "cid_set_compute_dtype": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_compute_dtype": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "cid_launch_work_ex": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "cid_stage_view": (_c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int),
                                   _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "cid_comm_unique_id": (_c.c_int, [_c.c_void_p]),

@@ -209,7 +209,7 @@ struct cid_handle_s {
     const float* dev_blob = nullptr;
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
-    int tail_algo = CID_TAIL_BANDS;    // last layer: row-band kernel (images up to 128 wide) or the tiled kernel everywhere
+    int tail_algo = CID_TAIL_FUSED;    // last layer: see cid_set_tail_algo
     int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: CID_ALGO_DIRECT (9-tap implicit GEMM) or Winograd F(2x2,3x3)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
@@ -221,6 +221,9 @@ struct cid_handle_s {
 };
 
 namespace {
+
+// The fused form needs the Winograd kernel of upconv1[0] (its epilogue does the contraction) and fp32 storage.
+bool fused_tail_active(cid_handle_t h) { return h->tail_algo == CID_TAIL_FUSED && h->algo == CID_ALGO_WINOGRAD64 && h->dtype == CID_DTYPE_F32; }
 
 int fail(cid_handle_t h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -285,6 +288,38 @@ hipError_t launch_wino64_tc(hipStream_t s, const WinoArgs& base) {
     return hipGetLastError();
 }
 
+// upconv1[0] with the channel contraction of upconv1[2] folded into its epilogue: z planes instead of the 64-channel tensor.
+template <int TC>
+hipError_t launch_wino64_z_tc(hipStream_t s, const WinoArgs& base) {
+    WinoArgs a = base;
+    constexpr int TRW = 32 / TC;
+    a.tiles_x = cdiv(a.Wc, 2 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
+    a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL((k_wino64_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_upconv1_0_z(hipStream_t s, const float* blob, const float* in, int Hc, int Wc, float* zout, int N) {
+    WinoArgs a;
+    a.in = in; a.u = blob + kBlob.u_off[10]; a.bias = blob + kBlob.b_off[10];
+    a.out = nullptr; a.pool = nullptr; a.zw = blob + kBlob.w_off[11]; a.zout = zout;
+    a.N = N; a.Hin = Hc; a.Win = Wc; a.in_ps = 128; a.Hc = Hc; a.Wc = Wc; a.Hs = Hc; a.Ws = Wc;
+    a.out_ps = 64; a.out_coff = 0;
+    a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
+    a.rcp_x = a.rcp_xy = 0;
+    a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
+    return Wc > 32 ? launch_wino64_z_tc<32>(s, a) : launch_wino64_z_tc<16>(s, a);
+}
+hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void* out, int N, int H, int W, bool u8) {
+    TailZArgs a;
+    a.z = z; a.bias = bias; a.out = out; a.N = N; a.H = H; a.W = W;
+    a.blocks_per_image = cdiv(H * W, THREADS);
+    a.rcp_w = tile_rcp((unsigned)W); a.rcp_blocks = tile_rcp((unsigned)a.blocks_per_image);
+    if (u8) hipLaunchKernelGGL((k_conv_tail_z<true>), dim3(N * a.blocks_per_image), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_tail_z<false>), dim3(N * a.blocks_per_image), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 // One 3x3 GEMM layer, by the handle's algorithm: MODE 0/1 of k_gemm_conv or Winograd.
 template <int CIN, int COUT, int MODE>
 hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer, const float* in, int Hin, int Win, int in_ps,
@@ -292,7 +327,7 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     if (algo == 0) return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
     WinoArgs a;
     a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.slot_tab = nullptr;
-    a.out = out; a.pool = pool;
+    a.out = out; a.pool = pool; a.zw = nullptr; a.zout = nullptr;
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
@@ -416,6 +451,13 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     STEP((launch_layer<128, 128, 0>(h, s, blob, 8, B[T3], d.Hu2, d.Wu2, 128, B[D2], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     // up1: ConvT 128->64 -> cat1[:, 0:64]                                                app.py:73,96
     STEP((launch_layer<128, 64, 2>(h, s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
+    const bool fused_tail = fused_tail_active(h);
+    if (fused_tail) {
+        // upconv1[0] + ReLU, with upconv1[2]'s channel contraction in its epilogue: z planes into the t4 region     app.py:75-77
+        STEP(launch_upconv1_0_z(s, blob, B[CAT1], d.Hu1, d.Wu1, B[T4], N));
+        // the nine-tap shifted sum + bias + tanh, -> NCHW out                              app.py:77,103
+        STEP(launch_tail_z(s, B[T4], blob + kBlob.b_off[11], out, N, d.Hu1, d.Wu1, out_fmt == CID_FMT_U8_NHWC));
+    } else {
     // upconv1[0] + ReLU                                                                  app.py:75-76
     STEP((launch_layer<128, 64, 0>(h, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
     // upconv1[2] + tanh, NHWC t4 -> NCHW out                                            app.py:77,103
@@ -434,6 +476,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         tile_groups(a);
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
         STEP(launch_tail(s, a, 8 * a.groups_per_xcd, out_fmt == CID_FMT_U8_NHWC, h->dtype == CID_DTYPE_F16));
+    }
     }
 #undef STEP
     if (ev && hipEventRecord(ev[NL], s) != hipSuccess) return fail(h, CID_ERR_HIP, "hipEventRecord failed");
@@ -670,7 +713,7 @@ int cid_set_conv_algo(cid_handle_t h, int algo) {
 }
 int cid_set_tail_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
-    if (algo != CID_TAIL_BANDS && algo != CID_TAIL_TILES) return fail(h, CID_ERR_INVALID, "cid_set_tail_algo: unknown algorithm");
+    if (algo != CID_TAIL_FUSED && algo != CID_TAIL_BANDS && algo != CID_TAIL_TILES) return fail(h, CID_ERR_INVALID, "cid_set_tail_algo: unknown algorithm");
     h->tail_algo = algo;
     return CID_OK;
 }
@@ -727,6 +770,8 @@ int cid_stage_view(const char* stage, int N, int H, int W, size_t* offset_bytes,
         {"up2", CAT2, 128, d.Hu2, d.Wu2, 256, 0},        //                                            app.py:89
         {"upconv2", D2, 128, d.Hu2, d.Wu2, 128, 0},      //                                            app.py:94
         {"up1", CAT1, 64, d.Hu1, d.Wu1, 128, 0},         //                                            app.py:96
+        {"upconv1.0", T4, 64, d.Hu1, d.Wu1, 64, 0},      // after its ReLU (app.py:75-76); with CID_TAIL_FUSED the region holds
+                                                         // the 27 z planes [N, 27, Hu1, Wu1] instead
     };
     for (const Row& r : rows)
         if (std::strcmp(stage, r.name) == 0) {
@@ -828,6 +873,27 @@ int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes) {
     *flops = 2.0 * L.cin * L.cout * taps * pix[i] * N;
     const double out_pix = L.kind == CONVT ? 4 * pix[i] : pix[i];
     *bytes = 4.0 * (N * (pix[i] * L.cin + out_pix * L.cout) + (double)ref_weight_count(L) + L.cout);
+    return CID_OK;
+}
+
+// The same per LAUNCH under the handle's configuration.  It differs from the per-layer figures only when the last layer's
+// channel contraction is fused into upconv1[0]'s launch (CID_TAIL_FUSED): launch 10 then carries the FLOPs of both layers and
+// writes 27 z planes instead of 64 channels; launch 11 is the shifted sum (no multiply-adds) over those planes.
+int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops, double* bytes) {
+    const int rc = cid_launch_work(i, N, H, W, flops, bytes);
+    if (rc != CID_OK || !h || !fused_tail_active(h) || i < 10) return rc;
+    Dims d;
+    make_dims(N, H, W, d);
+    const double px = (double)N * d.Hu1 * d.Wu1;
+    double f11, b11;
+    cid_launch_work(11, N, H, W, &f11, &b11);
+    if (i == 10) {
+        *flops += f11;
+        *bytes += 4.0 * px * (27 - 64) + 4.0 * ref_weight_count(kLayers[11]);
+    } else {
+        *flops = 0.0;
+        *bytes = 4.0 * (px * (27 + 3) + 3);
+    }
     return CID_OK;
 }
 

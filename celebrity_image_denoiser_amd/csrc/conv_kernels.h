@@ -1055,4 +1055,58 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail2(const Tail2Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail, third form (the default with the Winograd kernels): the producer, k_wino64_conv<128, 64, .., ZOUT>, has already
+// contracted the 64 channels, z[n][3*tap + co][y][x] (27 planes).  What is left of upconv1[2] + tanh (app.py:77,103) is
+//     out[n][co][y][x] = tanh(bias[co] + sum_{ty,tx} z[n][3*(3*ty+tx) + co][y+ty-1][x+tx-1])          (zero outside the image)
+// Every z element is read by exactly one output, so there is nothing to stage: one thread per pixel, 27 coalesced 4-byte
+// loads (plane = scalar offset, the nine shifted pixel offsets in registers, out-of-image taps carry an out-of-range
+// offset and read as zero), three tanh, three stores.  HBM-bound on 120 B per pixel (108 z + 12 out).
+struct TailZArgs {
+    const float* z;     // [N, 27, H, W]
+    const float* bias;  // [3]
+    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
+    int N, H, W;
+    int blocks_per_image;   // ceil(H*W / 256)
+    unsigned rcp_w, rcp_blocks;
+};
+template <bool OUT_U8>
+__global__ void __launch_bounds__(THREADS) k_conv_tail_z(const TailZArgs a) {
+    const unsigned b = blockIdx.x;
+    const unsigned n = a.rcp_blocks ? __umulhi(b, a.rcp_blocks) : b;
+    const unsigned p = (b - n * a.blocks_per_image) * THREADS + threadIdx.x;   // pixel index inside the image
+    const size_t plane = (size_t)a.H * a.W;
+    const unsigned y = a.rcp_w ? __umulhi(p, a.rcp_w) : p, x = p - y * a.W;
+    const bool inside = p < plane;
+    // descriptor over the image's 27 planes (<= 453 MB: H*W < 4,194,303, cid_api.hip shape_error); the scalar plane offset
+    // takes part in the hardware's range check on this part, so the descriptor cannot be a single plane
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)n * 27 * plane), (short)0, (int)(plane * 108), 0x00020000);
+    float o[3] = {a.bias[0], a.bias[1], a.bias[2]};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int yy = (int)y + ty - 1, xx = (int)x + tx - 1;
+            const bool ok = inside && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((yy * a.W + xx) * 4) : 0x7ffffff0u;
+#pragma unroll
+            for (int co = 0; co < 3; ++co)   // plane (3*tap + co) is a scalar offset; out-of-image taps: out-of-range vector offset
+                o[co] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, (int)(((3 * ty + tx) * 3 + co) * plane * 4), 0));
+        }
+    if (!inside) return;
+    if (OUT_U8) {
+        unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)n * plane + p) * 3;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
+            op[co] = (unsigned char)(v * 255.0f);
+        }
+    } else {
+        float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + p;
+        op[0] = tanhf(o[0]);
+        op[plane] = tanhf(o[1]);
+        op[2 * plane] = tanhf(o[2]);
+    }
+}
+
 }  // namespace cid

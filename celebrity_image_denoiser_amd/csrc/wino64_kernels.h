@@ -56,6 +56,8 @@ struct WinoArgs {
     const unsigned* slot_tab;   // per LDS slot of the raw tile: (row << 20 | column << 8 | channel group), ~0u = deliver zeros (host: wino_slot_table)
     float* out;         // [N, Hs, Ws, out_ps] (+ out_coff)
     float* pool;        // POOL: [N, Hc/2, Wc/2, COUT]
+    const float* zw;    // ZOUT: the NEXT layer's 64 -> 27 (tap x channel) weights, packed as for k_conv_tail
+    float* zout;        // ZOUT: planar [N, 27, Hs, Ws] instead of `out`
     int N, Hin, Win, in_ps;
     int Hc, Wc, Hs, Ws;
     int out_ps, out_coff;
@@ -68,8 +70,16 @@ constexpr int WN2 = 64;       // output channels per workgroup
 // ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue,
 // 2 B quads loaded once, 4 A operand built once, 8 no epilogue, 16 epilogue without the global stores, 32 no per-chunk
 // barrier, 64 no prologue DMA, 128 no de-phasing of the two workgroups of a CU, 256 s_memtime trace into a.pool (results stay correct).
-template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
+//
+// ZOUT (upconv1[0], the producer of the last layer's input): instead of storing its 64 output channels the workgroup
+// applies the channel contraction of the NEXT layer, upconv1[2] = Conv2d(64, 3, 3, padding=1) (app.py:77), to them while they
+// are still in LDS:  z[p][3*tap + co] = sum_ci relu(y[p][ci]) * W2[co][ci][tap]  — a [pixels x 64] x [64 x 27] product that has no
+// halo, 32 more MFMAs per wave after the 512 of the main loop — and stores z as 27 planes [N, 27, H, W].  The last layer is
+// then only the nine-tap shifted sum, bias and tanh (k_conv_tail_z): the 64-channel tensor (268 B per pixel written here and
+// read there) never exists, 108 B per pixel of z take its place.
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0, bool ZOUT = false>
 __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
+    static_assert(!ZOUT || (COUT == 64 && !POOL), "ZOUT contracts exactly the 64 channels of one column-block pair");
 #ifndef CID_EXPERIMENTS
     static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
@@ -428,10 +438,51 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
                 for (int bp = 0; bp < 2; ++bp)
                     stg[(ap * 32 + 2 * tl_of(rr) + bp) * WS32 + i] = fmaxf(y[ap][bp][rr] + bias_v, 0.f);
         }
-        wave_lds_fence();
         // staged pixel sp = a' * 32 + (2*tl + b'): the wave's 16 tiles are tile row WTR, tile columns WTC .. WTC+15
         constexpr int WTR = (16 * RH) / TC, WTC = (16 * RH) % TC;
         const int wy = y0 + 2 * WTR, wx = x0 + 2 * WTC;
+        if constexpr (ZOUT) {
+            // Waves (NT_W = 0, RH) and (NT_W = 1, RH) have staged the two channel halves of the SAME 64 pixels (2 rows x 32
+            // columns).  Wave (NT_W, RH) contracts row a' = NT_W: A fragments from both stagings (pixel stride 36 floats =
+            // 9 slots: conflict-free ds_read_b128), B = the packed 64 x 32 (27 used) weights, 32 MFMAs.
+            f32x4 zb[2][4];
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) zb[ck][g] = reinterpret_cast<const f32x4*>(a.zw)[(ck * 4 + g) * 64 + lane];
+            __syncthreads();                                    // both stagings are complete
+            f32x16 zacc;
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {
+                const float* src = reinterpret_cast<const float*>(lds) + (ck * 2 + RH) * (64 * WS32) + (NT_W * 32 + i) * WS32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(src + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ck == 0 && g == 0 && e == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], zb[ck][g][e], zero, 0, 0, 0);
+                        } else {
+                            zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], zb[ck][g][e], zacc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // lane (column j = i, half h) holds z[pixel (r&3) + 8*(r>>2) + 4*h][j]: registers 4q..4q+3 are four consecutive
+            // pixels of one row of plane j — one 16-byte store each (H, W are multiples of 4: a group is inside or outside)
+            const int yy = wy + NT_W;
+            if (i < 27 && yy < a.Hs && !(ABLATE & 16)) {
+                float* zrow = a.zout + (((size_t)n * 27 + i) * a.Hs + yy) * a.Ws;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xx = wx + 8 * q + 4 * h;
+                    if (xx < a.Ws) *reinterpret_cast<f32x4*>(zrow + xx) = f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]};
+                }
+            }
+            return;
+        }
+        wave_lds_fence();
         const int cbase = a.out_coff + nb * WN2 + NT_W * 32;
         const bool full = (y0 + 2 * TRW <= a.Hs) && (x0 + 2 * TC <= a.Ws);
         if (ABLATE & 16) {

@@ -286,17 +286,18 @@ class DenoiseGenerator(nn.Module):
 
     @property
     def tail_algo(self) -> str:
-        """"bands" (default: row-band kernel for the last layer, images up to 128 pixels wide) or "tiles" (the tiled kernel
-        everywhere).  Same function; both go through the parity tests."""
+        """"fused" (default: the last layer's channel contraction runs inside upconv1[0]'s Winograd kernel; with conv_algo
+        "direct" or compute_dtype "f16" it behaves as "bands"), "bands" (separate row-band kernel, images up to 128 pixels
+        wide) or "tiles" (round 1's tiled kernel).  Same function; all go through the parity tests."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_tail_algo(self._cid, ctypes.byref(a)))
-        return "tiles" if a.value == _lib.CID_TAIL_TILES else "bands"
+        return {_lib.CID_TAIL_TILES: "tiles", _lib.CID_TAIL_BANDS: "bands"}.get(a.value, "fused")
 
     @tail_algo.setter
     def tail_algo(self, name: str) -> None:
-        algo = {"bands": _lib.CID_TAIL_BANDS, "tiles": _lib.CID_TAIL_TILES}.get(name)
+        algo = {"fused": _lib.CID_TAIL_FUSED, "bands": _lib.CID_TAIL_BANDS, "tiles": _lib.CID_TAIL_TILES}.get(name)
         if algo is None:
-            raise ValueError("tail_algo must be 'bands' or 'tiles'")
+            raise ValueError("tail_algo must be 'fused', 'bands' or 'tiles'")
         _lib.check(self._cid, _lib.lib().cid_set_tail_algo(self._cid, algo))
 
     @property
@@ -330,13 +331,19 @@ class DenoiseGenerator(nn.Module):
 
 
 def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
-    """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes)] of one forward
-    (kernel symbols under `model`'s conv algorithm; direct kernels if no model is given)."""
+    """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes, executed flops)] of one forward, per LAUNCH under
+    `model`'s configuration (direct kernels, unfused, if no model is given).  Algorithmic = the direct-convolution count of
+    the reference layer(s) the launch computes; executed = what its MFMAs issue: the Winograd F(2x2,3x3) kernels run 16/36 of
+    their 3x3 layer's multiplies (a fused-in contraction of the next layer is executed as it stands)."""
     L = _lib.lib()
     rows = []
     handle = model._cid if model is not None else None
     for i in range(_lib.CID_NUM_LAUNCHES):
-        f, b = ctypes.c_double(), ctypes.c_double()
-        _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f), ctypes.byref(b)))
-        rows.append((L.cid_launch_name(i).decode(), L.cid_launch_kernel(handle, i).decode(), f.value, b.value))
+        f, b, f0, b0 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(None, L.cid_launch_work_ex(handle, i, n, h, w, ctypes.byref(f), ctypes.byref(b)))
+        _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f0), ctypes.byref(b0)))
+        kern = L.cid_launch_kernel(handle, i).decode()
+        own = min(f.value, f0.value)                       # the launch's own layer (0 for a launch that only sums)
+        executed = own * (16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
+        rows.append((L.cid_launch_name(i).decode(), kern, f.value, b.value, executed))
     return rows

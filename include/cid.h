@@ -172,17 +172,23 @@ int cid_get_compute_dtype(cid_handle_t h, int* dtype);
 int cid_set_conv_algo(cid_handle_t h, int algo);
 int cid_get_conv_algo(cid_handle_t h, int* algo);
 /*
- * Decomposition of the last layer (upconv1[2] + tanh, backend/app.py:77,103) on the fp32 path; same function either way:
- *   CID_TAIL_BANDS  a workgroup slides down a band of rows, the 64 -> 27 (tap x channel) product is computed once per
- *                   pixel (default; images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
- *   CID_TAIL_TILES  8x32-pixel tiles, the product is computed over each tile's halo (round 1's kernel)
+ * How the last layer (upconv1[2] = Conv2d(64,3,3,p=1) + tanh, backend/app.py:77,103) runs on the fp32 path; same function:
+ *   CID_TAIL_FUSED  (default) its 64 -> 27 (tap x channel) contraction runs in the epilogue of upconv1[0]'s kernel, on the
+ *                   tile still in LDS; the last launch is the nine-tap shifted sum + bias + tanh over 27 planes.  Needs
+ *                   CID_ALGO_WINOGRAD64 and CID_DTYPE_F32; otherwise the handle behaves as CID_TAIL_BANDS.
+ *   CID_TAIL_BANDS  separate kernel: a workgroup slides down a band of rows, the contraction is computed once per pixel
+ *                   (images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
+ *   CID_TAIL_TILES  separate kernel: 8x32-pixel tiles, the contraction is computed over each tile's halo (round 1's kernel)
  */
-enum { CID_TAIL_BANDS = 0, CID_TAIL_TILES = 1 };
+enum { CID_TAIL_FUSED = 0, CID_TAIL_BANDS = 1, CID_TAIL_TILES = 2 };
 int cid_set_tail_algo(cid_handle_t h, int algo);
 int cid_get_tail_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
+/* The same per LAUNCH under the handle's configuration: identical except with CID_TAIL_FUSED, where launch 10 also carries
+ * upconv1[2]'s FLOPs and writes 27 planes instead of 64 channels, and launch 11 only sums, adds the bias and applies tanh. */
+int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops, double* bytes);
 
 /*
  * Where the output of one of the reference module's stages lives in the workspace of an [N,3,H,W] forward (NHWC,

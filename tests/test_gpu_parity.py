@@ -39,8 +39,8 @@ def models(request, weight_sets):
     for k, v in weight_sets.items():
         m = cid.load(v, device="cuda:0", strict=True)
         m.conv_algo = request.param
-        m.tail_algo = "tiles" if request.param == "direct" else "bands"
-        assert m.conv_algo == request.param and m.tail_algo == ("tiles" if request.param == "direct" else "bands")
+        m.tail_algo = "tiles" if request.param == "direct" else "fused"
+        assert m.conv_algo == request.param and m.tail_algo == ("tiles" if request.param == "direct" else "fused")
         out[k] = m
     return out
 
@@ -266,6 +266,31 @@ def test_host_roundtrip_and_batch_split(models):
     x = torch.from_numpy(synth.make_batch(3, 32, 32)[0])
     y_split = cid.denoise(models["hot"], x, max_batch=2)
     assert y_split.device.type == "cpu" and torch.equal(y_split, cid.denoise(models["hot"], x))
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_row_band_tail_kernel(weight_sets, golden_dir, wset):
+    """The separate row-band kernel for the last layer (tail_algo="bands": what the fused default falls back to when the
+    3x3 layers run as direct GEMMs): golden fixtures incl. the crop/ragged ones, a multi-band batch, uint8 output."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+
+    m = cid.load(weight_sets[wset], device="cuda:0", strict=True)
+    m.tail_algo = "bands"
+    assert m.tail_algo == "bands"
+    for name in ("16x16", "20x24", "13x18", "7x9", "4x4"):
+        g = np.load(os.path.join(golden_dir, f"tiny_{wset}_{name}.npz"))
+        assert np.abs(_run(m, g["x"]) - g["out"]).max() <= TOL, name
+    g = np.load(os.path.join(golden_dir, f"full_{wset}_128.npz"))
+    x, _, noisy = synth.make_batch(2, 128, 128, 100)
+    assert np.abs(_run(m, x) - g["out"]).max() <= TOL
+    gu = np.load(os.path.join(golden_dir, f"u8_{wset}_32x40.npz"))
+    d = np.abs(m.forward_u8(torch.from_numpy(gu["noisy_u8"]).to("cuda:0")).cpu().numpy().astype(np.int16) - gu["out_u8"].astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+    xb, _, _ = synth.make_batch(9, 100, 72, first_index=3300)          # several bands per image, ragged width
+    ref = cid.load(weight_sets[wset], device="cuda:0", strict=True)
+    ref.tail_algo = "tiles"
+    assert np.abs(_run(m, xb) - _run(ref, xb)).max() <= TOL
 
 
 def test_winograd_and_direct_agree(weight_sets):
