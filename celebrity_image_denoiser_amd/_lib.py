@@ -5,7 +5,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcid.so")
+# CID_LIB_PATH: development aid for same-box A/B runs of two builds of the library (bench.py in alternation)
+LIB_PATH = os.environ.get("CID_LIB_PATH") or os.path.join(_HERE, "libcid.so")
 
 CID_OK = 0
 CID_NUM_PARAMS = 24
