@@ -10,6 +10,11 @@
 //   * workgroup = 8x32 output pixels x 64 channels, wave = 64 pixels x 64 channels (2x2 MFMA tiles);
 //   * K = (32-channel chunk) x (tap) x (16-channel k-step); per k-step and wave: two ds_read_b128 (A: lane
 //     (i,h) takes channels 8h..8h+7 of pixel i) and two 1 KiB B quads (pre-packed per lane), four MFMAs;
+//   * 3x3 layers: the B quads of a chunk (36 KiB, identical for the four waves) come through LDS — fetched once per
+//     workgroup, global -> registers one 16-byte piece per thread and k-step under the previous chunk's MFMAs, written
+//     to LDS at the chunk seam beside the halo tile.  Round 1 had every wave fetch its own copy from L2: 128 B/clk
+//     per CU of B traffic against ~56 B/clk of L2 bandwidth, which capped those layers at 0.33-0.43 of the MFMA rate.
+//     The transposed convolutions (one tap: 4 KiB of B per chunk) keep the per-wave fetch;
 //   * LDS halo tile: pixel = 64 B of data + 16 B pad (5 slots): consecutive pixels are conflict-free for
 //     ds_read_b128; fetched global -> registers -> LDS one piece per step under the MFMAs, like k_gemm_conv;
 //   * store tail: fp32 staging in LDS (wide_store layout), converted to half on the way out, 16 B per lane.
@@ -45,8 +50,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     constexpr int NB = NOUT / NTILE;
     constexpr int SPC = TAPS * 2;                    // k-steps (16 channels each) per chunk
     static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0, "layer dims");
-    constexpr int LDS_SLOTS = (LPIX * HPS * 16 > 4 * WS_FLOATS * 4) ? LPIX * HPS : (4 * WS_FLOATS * 4 + 15) / 16;
-    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile (half), later the fp32 store staging
+    constexpr bool BLDS = MODE != 2;                 // B through LDS (3x3 layers)
+    constexpr int BSLOTS = BLDS ? SPC * 2 * 64 : 0;  // 16-byte B quads of one chunk: [k-step][ns][lane]
+    constexpr int NBL = BSLOTS / THREADS;            // B pieces per thread and chunk (9)
+    static_assert(BSLOTS % THREADS == 0, "B chunk is a whole number of 4 KiB pieces");
+    constexpr int HALO_SLOTS = LPIX * HPS;
+    constexpr int LDS_SLOTS = ((HALO_SLOTS + BSLOTS) * 16 > 4 * WS_FLOATS * 4) ? HALO_SLOTS + BSLOTS : (4 * WS_FLOATS * 4 + 15) / 16;
+    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile (half) | B chunk (half); later the fp32 store staging
 
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
@@ -99,23 +109,41 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     auto b_load = [&](int gstep, int ns) -> f16x8 {   // step g is the 2 KiB at (nb*NCHUNK*SPC + g)*2048 bytes
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, wbase + gstep * 2048 + ns * 1024, 0));
     };
+    // BLDS: piece j of chunk ck = the 4 KiB at byte (chunk base) + 4096 j, 16 bytes per thread; it lands in B slot 256 j + tid
+    auto bpiece_load = [&](int j, int ck) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase + ck * SPC * 2048 + j * 4096, 0));
+    };
+    f32x4* const ldsb = lds + HALO_SLOTS;
 
     f32x4 pre[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
+    f32x4 bpre[BLDS ? NBL : 1];
     f16x8 bcur[2], bnxt[2];
-    bcur[0] = b_load(0, 0);
-    bcur[1] = b_load(0, 1);
+    if (BLDS) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) bpre[j] = bpiece_load(j, 0);
+    } else {
+        bcur[0] = b_load(0, 0);
+        bcur[1] = b_load(0, 1);
+    }
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+    if (BLDS) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
+    }
     __syncthreads();
 
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
+    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;   // B quad (k-step st, ns) of this lane at [(2 st + ns) * 64]
+    static_assert(!BLDS || NLOAD + NBL <= SPC, "one prefetch piece per k-step");
     auto chunk = [&](auto pref_tag, int ck) {
         constexpr bool PREF = decltype(pref_tag)::value;
         f16x8 acur[2], anxt[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * HPS];
+        if (BLDS) { bcur[0] = ldsbh[0]; bcur[1] = ldsbh[64]; }
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
             if (st + 1 < SPC) {
@@ -124,7 +152,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
 #pragma unroll
                 for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + off];
             }
-            if (PREF || st + 1 < SPC) {
+            if (BLDS) {
+                if (st + 1 < SPC) { bnxt[0] = ldsbh[(2 * (st + 1)) * 64]; bnxt[1] = ldsbh[(2 * (st + 1) + 1) * 64]; }
+                if (PREF && st >= NLOAD && st - NLOAD < NBL) bpre[st - NLOAD] = bpiece_load(st - NLOAD, ck + 1);
+            } else if (PREF || st + 1 < SPC) {
                 bnxt[0] = b_load(ck * SPC + st + 1, 0);
                 bnxt[1] = b_load(ck * SPC + st + 1, 1);
             }
@@ -138,7 +169,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
             }
-            if (PREF || st + 1 < SPC) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
+            if (BLDS ? (st + 1 < SPC) : (PREF || st + 1 < SPC)) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
         }
         if (PREF) {
             if (SPC < NLOAD) {
@@ -148,6 +179,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
+            if (BLDS) {
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
+            }
             __syncthreads();
         }
     };
