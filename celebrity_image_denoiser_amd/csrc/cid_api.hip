@@ -36,9 +36,9 @@ const char* kKernelNames[NL] = {
 };
 
 const char* kHalfKernelNames[NL] = {
-    "k_conv_head", "k_gemm_conv_h<64, 64, 1>", "k_gemm_conv_h<64, 128, 0>", "k_gemm_conv_h<128, 128, 1>",
-    "k_gemm_conv_h<128, 256, 0>", "k_gemm_conv_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_gemm_conv_h<256, 128, 0>",
-    "k_gemm_conv_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_gemm_conv_h<128, 64, 0>", "k_conv_tail_h",
+    "k_conv_head", "k_conv3x3_h<64, 64, 1>", "k_conv3x3_h<64, 128, 0>", "k_conv3x3_h<128, 128, 1>",
+    "k_conv3x3_h<128, 256, 0>", "k_conv3x3_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_conv3x3_h<256, 128, 0>",
+    "k_conv3x3_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_conv3x3_h<128, 64, 0>", "k_conv_tail_h",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -388,7 +388,8 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
-    hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    if constexpr (MODE == 2) hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 

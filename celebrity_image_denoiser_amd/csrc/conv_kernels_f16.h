@@ -38,6 +38,60 @@ struct GemmConvArgsH {
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
+// Epilogue shared by the fp16 GEMM kernels: bias (+ReLU) (+2x2 max-pool) (+transposed-conv pixel scatter) on the fp32
+// accumulators, one rounding to half, 16-byte stores through the LDS staging of wide_store_h.
+template <int COUT, int MODE, typename Args>
+__device__ __forceinline__ void gemm_h_epilogue(const Args& a, f32x4* lds, f32x16 (&acc)[2][2], const float (&bias_v)[2], int n, int y0, int x0,
+                                                int wave, int lane, int h, int tap2, int cobase) {
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
+    if (MODE == 2) {
+        const int kh = tap2 >> 1, kw = tap2 & 1;
+        const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
+            const int step = 2 * a.out_ps;
+            const bool rowok = y < a.Hc;
+            auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
+            if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
+                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
+            else
+                wide_store_h<32>(stg, lane, val, xo,
+                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
+            const bool rowok = y < a.Hs;
+            auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
+            if (y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws)
+                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * a.out_ps, a.out_ps);
+            else
+                wide_store_h<32>(stg, lane, val, xo,
+                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
+        }
+        if (MODE == 1) {
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+            const int py = (y0 >> 1) + wave;
+            _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase;
+            const bool rowok = py < Hp;
+            wide_store_h<16>(stg, lane,
+                             [&](int ns, int q) {
+                                 const int r = (q & 1) * 2 + (q >> 1) * 4;
+                                 const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
+                                 return fmaxf(v + bias_v[ns], 0.f);
+                             },
+                             [&](int q) { return (q & 1) + 4 * (q >> 1) + 2 * h; },
+                             [&](int px) -> _Float16* { return (rowok && (x0 >> 1) + px < Wp) ? prow + (size_t)((x0 >> 1) + px) * COUT : nullptr; });
+        }
+    }
+}
+
 template <int CIN, int COUT, int MODE>
 __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH a) {
     constexpr int TAPS = (MODE == 2) ? 1 : 9;
@@ -189,54 +243,149 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
     chunk(std::false_type{}, NCHUNK - 1);
 
-    // ---- epilogue (same structure as k_gemm_conv) ----
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
-    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
-    if (MODE == 2) {
-        const int kh = tap2 >> 1, kw = tap2 & 1;
-        const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+    gemm_h_epilogue<COUT, MODE>(a, lds, acc, bias_v, n, y0, x0, wave, lane, h, tap2, cobase);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 layers of the fp16-storage path, second form: 16-channel chunks, three workgroups per CU.
+//
+// With fp16 MFMA a workgroup's main loop is short (CIN = 128: 288 MFMAs = 9k cycles per wave) next to its prologue
+// (first loads: memory latency) and epilogue (conversion, staging, 32 KiB of stores), so what bounds these layers is how many
+// workgroups a CU can interleave.  k_gemm_conv_h holds a 32-channel halo tile plus the chunk's B quads in 64 KiB of LDS:
+// two per CU.  Here a chunk is 16 channels (one MFMA k-step per tap): halo tile 340 pixels x 48 B (32 B data + 16 B pad:
+// three 16-byte slots, conflict-free for ds_read_b128) + 18 KiB of B = 34 KiB, under 168 VGPRs: three per CU.
+// Same tile (8x32 pixels x 64 channels, wave = 2 rows), same packed weights (a 16-channel chunk is k-step `ks` of the
+// 32-channel chunk `ck32`: its quads (tap, ns) lie 4 KiB apart), same epilogue.
+template <int CIN, int COUT, int MODE>
+__global__ void __launch_bounds__(THREADS, MODE == 0 ? 4 : 3) k_conv3x3_h(const GemmConvArgsH a) {
+    static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
+    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;
+    constexpr int PS3 = 3;                           // LDS slots per pixel: 2 data (16 halfs) + 1 pad
+    constexpr int NSLOT = LPIX * 2;                  // 16-byte data slots per chunk tile
+    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 3
+    constexpr int NCHUNK = CIN / 16, NCH32 = CIN / 32;
+    constexpr int NB = COUT / NTILE;
+    constexpr int SPC = 9;                           // k-steps per chunk = taps
+    constexpr int BSLOTS = SPC * 2 * 64;             // B quads of one chunk: [tap][ns][lane]
+    constexpr int NBL = (BSLOTS + THREADS - 1) / THREADS;    // 5 pieces per thread (the last one half used)
+    constexpr int HALO_SLOTS = LPIX * PS3;
+    constexpr int LDS_SLOTS = ((HALO_SLOTS + BSLOTS) * 16 > 4 * WS_FLOATS * 4) ? HALO_SLOTS + BSLOTS : (4 * WS_FLOATS * 4 + 15) / 16;
+    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile | B chunk; later the fp32 store staging (34,816 B)
+
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int cobase = nb * NTILE;
+    float bias_v[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = y0 + 2 * wave + m;
-            _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
-            const int step = 2 * a.out_ps;
-            const bool rowok = y < a.Hc;
-            auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
-            if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
-                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
-            else
-                wide_store_h<32>(stg, lane, val, xo,
-                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
-        }
-    } else {
+    for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
+
+    // halo pieces: data slot s = it*256 + tid = (pixel s>>1, half-chunk s&1); out-of-image pieces read as zero (range check)
+    const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
+    unsigned goff[NLOAD];
+    int hslot[NLOAD];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = y0 + 2 * wave + m;
-            _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
-            const bool rowok = y < a.Hs;
-            auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
-            if (y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws)
-                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * a.out_ps, a.out_ps);
-            else
-                wide_store_h<32>(stg, lane, val, xo,
-                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
-        }
-        if (MODE == 1) {
-            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-            const int py = (y0 >> 1) + wave;
-            _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase;
-            const bool rowok = py < Hp;
-            wide_store_h<16>(stg, lane,
-                             [&](int ns, int q) {
-                                 const int r = (q & 1) * 2 + (q >> 1) * 4;
-                                 const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
-                                 return fmaxf(v + bias_v[ns], 0.f);
-                             },
-                             [&](int q) { return (q & 1) + 4 * (q >> 1) + 2 * h; },
-                             [&](int px) -> _Float16* { return (rowok && (x0 >> 1) + px < Wp) ? prow + (size_t)((x0 >> 1) + px) * COUT : nullptr; });
-        }
+    for (int it = 0; it < NLOAD; ++it) {
+        const int s = it * THREADS + tid;
+        const int p = s >> 1, c = s & 1;
+        const int hy = p / LW, hx = p - hy * LW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 8) * 2) : 0x7ffffff0u;
+        hslot[it] = s < NSLOT ? p * PS3 + c : -1;
     }
+    auto halo_load = [&](int it, int ck) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * 32, 0));
+    };
+    // B pieces: slot = j*256 + tid = quad (tap, ns) = slot >> 6, lane = slot & 63; in the packed weights quad (tap, ns) of the
+    // 16-channel chunk (ck32, ks) is the 1 KiB at ((ck32*9 + tap)*4 + ks*2 + ns) * 1024 past the column block's base
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
+    const int wbase = nb * NCH32 * 36 * 1024;
+    unsigned boff[NBL];
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) {
+        const int slot = j * THREADS + tid, quad = slot >> 6;
+        boff[j] = slot < BSLOTS ? (unsigned)(((quad >> 1) * 4 + (quad & 1)) * 1024 + (slot & 63) * 16) : 0x7ffffff0u;
+    }
+    auto b_load = [&](int j, int ck) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, boff[j], wbase + ((ck >> 1) * 36 + (ck & 1) * 2) * 1024, 0));
+    };
+    f32x4* const ldsb = lds + HALO_SLOTS;
+    auto stage_to_lds = [&](const f32x4 (&pre)[NLOAD], const f32x4 (&bpre)[NBL]) {
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it)
+            if (hslot[it] >= 0) lds[hslot[it]] = pre[it];
+#pragma unroll
+        for (int j = 0; j < NBL; ++j)
+            if ((j + 1) * THREADS <= BSLOTS || j * THREADS + tid < BSLOTS) ldsb[j * THREADS + tid] = bpre[j];
+    };
+
+    f32x4 pre[NLOAD], bpre[NBL];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) bpre[j] = b_load(j, 0);
+    f32x16 acc[2][2];
+    stage_to_lds(pre, bpre);
+    __syncthreads();
+
+    const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
+    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;   // B quad (tap, ns) of this lane at [(2 tap + ns) * 64]
+    const int pbase0 = ((2 * wave) * LW + i) * PS3 + h;                 // slot of (row 2*wave, column i), tap (0,0)
+    auto chunk = [&](auto first_tag, auto pref_tag, int ck) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool PREF = decltype(pref_tag)::value;
+        f16x8 acur[2], anxt[2], bcur[2], bnxt[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * PS3];
+        bcur[0] = ldsbh[0]; bcur[1] = ldsbh[64];
+        if (PREF) {   // the whole next chunk is requested before this chunk's first MFMA: at fp16 rates a chunk is only ~1-3k cycles of
+                      // matrix work, and a request issued in its middle would still be in flight at the seam
+#pragma unroll
+            for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, ck + 1);
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) bpre[j] = b_load(j, ck + 1);
+        }
+#pragma unroll
+        for (int st = 0; st < SPC; ++st) {
+            if (st + 1 < SPC) {
+                const int off = (((st + 1) / 3) * LW + ((st + 1) % 3)) * PS3;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * PS3 + off];
+                bnxt[0] = ldsbh[(2 * (st + 1)) * 64]; bnxt[1] = ldsbh[(2 * (st + 1) + 1) * 64];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns) {
+                    if (FIRST && st == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], zero, 0, 0, 0);
+                    } else {
+                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], acc[m][ns], 0, 0, 0);
+                    }
+                }
+            if (st + 1 < SPC) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
+                bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
+            }
+        }
+        if (PREF) {
+            __syncthreads();          // every wave is done reading this chunk's tile and B
+            stage_to_lds(pre, bpre);
+            __syncthreads();
+        }
+    };
+    static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
+    chunk(std::true_type{}, std::true_type{}, 0);
+    for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
+    chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
+    gemm_h_epilogue<COUT, MODE>(a, lds, acc, bias_v, n, y0, x0, wave, lane, h, 0, cobase);
 }
 
 // ---------------------------------------------------------------------------------------------

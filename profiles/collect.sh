@@ -8,8 +8,9 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
-SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+# BENCH_ARGS: extra bench.py arguments (e.g. "--dtype f16 --batch-per-gpu 512" for BASELINE configs[4])
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS"
+SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || { echo "stats pass failed"; tail -5 "$OUT/stats.err"; exit 1; }
 echo "stats pass done"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_sq" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $SHORT > "$OUT/bench_pmc_sq.json" 2> "$OUT/pmc_sq.err" || { echo "pmc sq pass failed"; tail -5 "$OUT/pmc_sq.err"; exit 1; }
