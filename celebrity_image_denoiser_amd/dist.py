@@ -82,7 +82,28 @@ def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dis
         if rank != src:
             model.adopt_packed_weights(blob, update_parameters=True)
         return
-    comm = WeightsComm(dev, group)
+    # Transport 1: ncclBroadcast issued by libcid.so on its own communicator (cid_broadcast_weights).  Transport 2, only if
+    # the first cannot be set up on this host (no RCCL found at run time, communicator creation refused): the same bytes as
+    # ONE torch.distributed.broadcast on the process group's backend (nccl = the same RCCL over xGMI).  Either way it is one
+    # collective of the packed blob; every rank takes the same branch (the choice is agreed on with an all-reduce).
+    import logging
+
+    comm, ok = None, 1
+    try:
+        comm = WeightsComm(dev, group)
+    except Exception as e:   # noqa: BLE001 - any set-up failure selects transport 2 on ALL ranks
+        logging.getLogger("cid").warning("cid_comm_* unavailable (%s): broadcasting the blob with torch.distributed", e)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        blob = model.pack_weights() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dist.broadcast(blob, src=src, group=group)
+        if rank != src:
+            model.adopt_packed_weights(blob, update_parameters=True)
+        return
     try:
         if rank == src:
             blob = model.pack_weights()

@@ -189,11 +189,53 @@ class DenoiseGenerator(nn.Module):
         """[N,3,H,W] fp32 in [-1,1] on the GPU -> [N,3,4*(H//4),4*(W//4)] fp32 in (-1,1).
         Same contract as the reference forward (app.py:80-103); asynchronous on the current stream.
         `out=` (not in the reference) writes into a caller-owned tensor instead of allocating."""
+        if isinstance(x, torch.Tensor) and x.dim() == 4 and self._needs_stripes(x.shape[2], x.shape[3]):
+            return self._forward_striped(x, out_u8=False, out=out)
         x, y, n, h, w = self._prepare(x, out)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(self._cid, _lib.lib().cid_forward(self._cid, x.data_ptr(), y.data_ptr(), n, h, w,
                                                          self._ws.data_ptr(), self._ws.numel(), stream))
+        return y
+
+    # ------------------------------------------------------------------ images beyond one call's size limit
+    # The kernels address one image's activations with 32-bit byte offsets: cid_forward refuses H*W >= 4,194,303 pixels
+    # (include/cid.h; 2048x2048 is the first square that does not fit).  The reference takes any size (app.py:80-103 is fully
+    # convolutional), so larger images are cut into horizontal stripes here: output rows [a, b) (multiples of 8) are computed
+    # from input rows [a - 32, b + 32).  A network output depends on input rows within +-20 (2 + 4 + 8 + 4 + 2 rows through
+    # the three resolutions, plus pool alignment), stripe origins are multiples of 8 (pool windows, transposed-conv phases
+    # and the 2x2 Winograd tiles keep their alignment down to the quarter-resolution layers: a pixel that changed its place
+    # inside a Winograd tile would be summed in another order), and every pixel is computed by the same instructions, so
+    # the assembled result equals the single-call result bit for bit (tests: forced small stripes on a mid-size image).
+    STRIPE_HALO = 32
+    MAX_PIXELS_PER_CALL = 0x7ffffff0 // 512 - 1
+
+    def _needs_stripes(self, h: int, w: int) -> bool:
+        return h * w > self.MAX_PIXELS_PER_CALL
+
+    def _forward_striped(self, x: torch.Tensor, out_u8: bool, out: torch.Tensor = None, stripe_rows: int = None) -> torch.Tensor:
+        in_u8 = x.dtype == torch.uint8
+        n = x.shape[0]
+        h, w = (x.shape[1], x.shape[2]) if in_u8 else (x.shape[2], x.shape[3])
+        if h < 4 or w < 4:
+            raise RuntimeError(f"Given input size: ({h}x{w}). Calculated output size is too small (H and W must be >= 4)")
+        ho, wo = 4 * (h // 4), 4 * (w // 4)
+        halo = self.STRIPE_HALO
+        if stripe_rows is None:
+            stripe_rows = (self.MAX_PIXELS_PER_CALL // w - 2 * halo) // 8 * 8
+        if stripe_rows < 8 or stripe_rows % 8:
+            raise RuntimeError(f"image rows of {w} pixels are too wide to cut into stripes of at least 8 rows")
+        shape = (n, ho, wo, 3) if out_u8 else (n, 3, ho, wo)
+        y = self._output(out, shape, torch.uint8 if out_u8 else torch.float32, x.device)
+        for a in range(0, ho, stripe_rows):
+            b = min(a + stripe_rows, ho)
+            i0, i1 = max(0, a - halo), (h if b == ho else min(h, b + halo))
+            xs = (x[:, i0:i1] if in_u8 else x[:, :, i0:i1]).contiguous()
+            ys = self.forward_fmt(xs, out_u8=out_u8)
+            if out_u8:
+                y[:, a:b] = ys[:, a - i0:b - i0]
+            else:
+                y[:, :, a:b] = ys[:, :, a - i0:b - i0]
         return y
 
     def forward_u8(self, images: torch.Tensor, out_u8: bool = True, out: torch.Tensor = None) -> torch.Tensor:
@@ -222,6 +264,8 @@ class DenoiseGenerator(nn.Module):
             raise RuntimeError(f"input on {x.device} but module parameters on {self._device()}")
         n = x.shape[0]
         h, w = (x.shape[1], x.shape[2]) if in_u8 else (x.shape[2], x.shape[3])
+        if n >= 1 and self._needs_stripes(h, w):
+            return self._forward_striped(x, out_u8=out_u8, out=out)
         L = _lib.lib()
         ho, wo = ctypes.c_int(), ctypes.c_int()
         if n < 1 or L.cid_out_shape(h, w, ctypes.byref(ho), ctypes.byref(wo)) != _lib.CID_OK:

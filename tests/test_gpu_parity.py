@@ -597,6 +597,48 @@ def test_rccl_broadcast_through_the_c_abi(weight_sets):
 
 
 
+def test_striped_forward_equals_single_call_bit_for_bit(models):
+    """Images beyond one call's size limit (cid_forward refuses H*W >= 4,194,303: 32-bit per-image addressing) are cut into
+    horizontal stripes with a 32-row halo (generator._forward_striped).  Property: with stripes FORCED on a mid-size image
+    the assembled result is the single-call result, bit for bit — fp32 and uint8 formats, a height that is not a multiple
+    of 4 (crop path at the bottom), stripes of 8, 16 and 56 rows (multiples of 8: Winograd tile alignment at quarter resolution)."""
+    m = models["hot"]
+    x, _, noisy = synth.make_batch(2, 150, 70, first_index=6000)
+    xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
+    want, want8 = m(xd).clone(), m.forward_u8(ud).clone()
+    for rows in (8, 16, 56):
+        assert torch.equal(m._forward_striped(xd, out_u8=False, stripe_rows=rows), want), (rows, float((m._forward_striped(xd, out_u8=False, stripe_rows=rows) - want).abs().max()))
+        assert torch.equal(m._forward_striped(ud, out_u8=True, stripe_rows=rows), want8), rows
+    with pytest.raises(RuntimeError):
+        m._forward_striped(xd, out_u8=False, stripe_rows=12)
+
+
+def test_image_beyond_the_single_call_limit(models, weight_sets):
+    """2048x2080 (the ADVICE r1 case: accepted in round 1, with real activations read as zero padding): now striped
+    automatically.  Checked against the CPU oracle on two windows cut around a stripe seam and at the bottom edge — a window
+    with 40 rows of context reproduces the full image's values there (receptive field +-20 rows)."""
+    from oracle import torch_oracle
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~40 GiB of free device memory")
+    m = models["default"]
+    h, w = 2080, 2048
+    assert m._needs_stripes(h, w)
+    rng = np.random.default_rng(11)
+    x = (rng.random((1, 3, h, w), dtype=np.float32) * 2 - 1)
+    y = m(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+    assert y.shape == (1, 3, h, w) and np.isfinite(y).all()
+    rows_per = (m.MAX_PIXELS_PER_CALL // w - 2 * m.STRIPE_HALO) // 8 * 8
+    for r0 in (rows_per - 8, h - 16):          # across the first seam; the bottom edge
+        lo, hi = max(0, r0 - 40) // 4 * 4, min(h, r0 + 16 + 40)
+        ref = torch_oracle.forward(weight_sets["default"], x[:, :, lo:hi, 512:768 + 64]).numpy()
+        got = y[:, :, r0:r0 + 16, 512 + 32:768 + 32]
+        assert np.abs(got - ref[:, :, r0 - lo:r0 - lo + 16, 32:-32]).max() <= TOL, r0
+    m._ws = None
+    torch.cuda.empty_cache()
+
+
 def test_batch_past_2_31_elements_per_buffer(models):
     """Maximum-size edge: 2080 images of 128x128 make the 64-channel buffers hold more than 2^31 elements (60 GiB arena).
     Every 16-image group must equal the same 16 images run alone, bit for bit (64-bit base addresses, 32-bit per-image
