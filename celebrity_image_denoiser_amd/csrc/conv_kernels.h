@@ -92,6 +92,12 @@ __device__ __forceinline__ void decode_tile(int mt, int tiles_x, int tiles_y, un
 // bytes), 4 pixels per instruction — a quarter of the store instructions at the same bytes.
 constexpr int WS_STRIDE = 68;                 // floats per staged pixel row (64 + 4: ds_write_b32 of 32 lanes conflict-free)
 constexpr int WS_FLOATS = 32 * WS_STRIDE;     // staging floats per wave
+// fp32 stores read the staging 16 lanes per pixel (ds_read_b128, four pixels per instruction): with an UNPADDED pixel row
+// (64 floats = 16 slots) the 16 lanes of every service group cover 16 different four-bank columns; at 68 floats the second
+// pixel of a group is shifted by one slot onto a column of the first (PMC: 21.7 % of the head's LDS cycles were conflicts).
+// The 32-lane ds_write_b32 of the accumulators is conflict-free at either stride.  Same-box A/B: the head gains 0.9 % with 64,
+// the transposed convolutions lose 0.7-1.7 % (they keep 68): the stride is a template parameter of the fp32 store helpers.
+constexpr int WS_UNPADDED = 64;
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -103,20 +109,20 @@ __device__ __forceinline__ void wave_lds_fence() {
 // 32*ns + (lane&31) for the k-th staged pixel of this lane (k in [0, NPIX/2)), `pix(k)` its pixel index
 // in [0, NPIX); `ptr(px)` returns the global address of channel 0 of the slab for pixel px, or nullptr
 // to skip it.
-template <int NPIX, typename ValFn, typename PixFn, typename PtrFn>
+template <int NPIX, int WSF = WS_STRIDE, typename ValFn, typename PixFn, typename PtrFn>
 __device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixFn pix, PtrFn ptr) {
     const int i = lane & 31;
 #pragma unroll
     for (int k = 0; k < NPIX / 2; ++k) {
         const int px = pix(k);
-        stg[px * WS_STRIDE + i] = val(0, k);
-        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+        stg[px * WSF + i] = val(0, k);
+        stg[px * WSF + 32 + i] = val(1, k);
     }
     wave_lds_fence();
 #pragma unroll
     for (int it = 0; it < NPIX / 4; ++it) {
         const int px = it * 4 + (lane >> 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 15) * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * WSF + (lane & 15) * 4);
         float* g = ptr(px);
         if (g) *reinterpret_cast<f32x4*>(g + (lane & 15) * 4) = v;
     }
@@ -151,20 +157,20 @@ __device__ __forceinline__ void wide_store_h(float* stg, int lane, ValFn val, Pi
 
 // Interior-tile variants: the slab's pixels are `stride` floats (halfs) apart starting at the wave-uniform `base`, all in
 // range.  One per-lane offset for the whole tail, the rest is scalar: no per-pixel pointer or bounds arithmetic.
-template <int NPIX, typename ValFn, typename PixFn>
+template <int NPIX, int WSF = WS_STRIDE, typename ValFn, typename PixFn>
 __device__ __forceinline__ void wide_store_full(float* stg, int lane, ValFn val, PixFn pix, float* base, int stride) {
     const int i = lane & 31;
 #pragma unroll
     for (int k = 0; k < NPIX / 2; ++k) {
         const int px = pix(k);
-        stg[px * WS_STRIDE + i] = val(0, k);
-        stg[px * WS_STRIDE + 32 + i] = val(1, k);
+        stg[px * WSF + i] = val(0, k);
+        stg[px * WSF + 32 + i] = val(1, k);
     }
     wave_lds_fence();
     const int lane_off = (lane >> 4) * stride + (lane & 15) * 4;
 #pragma unroll
     for (int it = 0; it < NPIX / 4; ++it) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * WS_STRIDE + (lane & 15) * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * WSF + (lane & 15) * 4);
         *reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off) = v;
     }
     wave_lds_fence();
@@ -613,9 +619,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
                 } else {
                     float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
                     if (full)
-                        wide_store_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
+                        wide_store_full<16, WS_UNPADDED>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
                     else
-                        wide_store<16>(stg, lane, val, pix,
+                        wide_store<16, WS_UNPADDED>(stg, lane, val, pix,
                                        [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
                 }
             }
