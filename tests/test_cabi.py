@@ -87,6 +87,47 @@ def test_algorithmic_work_matches_survey():
     assert b.value == 4390912 + (3 * 64 * 9 + 64) * 4      # a1: 4,390,912 activation bytes/img + weights
 
 
+def test_stage_views_and_fused_launch_accounting():
+    """cid_stage_view: where the reference module's hook outputs lie in the workspace (per-stage GPU parity reads them back);
+    cid_launch_work_ex: per-LAUNCH work under the handle's configuration — with the default fused last layer, launch 10
+    carries upconv1[0] + upconv1[2] and writes 27 planes, launch 11 only sums; the totals over the forward do not change."""
+    L = _lib.lib()
+    off, c, hs, ws, ps, co = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    args = (ctypes.byref(off), ctypes.byref(c), ctypes.byref(hs), ctypes.byref(ws), ctypes.byref(ps), ctypes.byref(co))
+    assert L.cid_stage_view(b"down1", 2, 13, 18, *args) == 0
+    assert (c.value, hs.value, ws.value, ps.value, co.value) == (64, 12, 16, 128, 64)      # skip tensor: cropped, upper half of cat1
+    t0_floats = 2 * 13 * 18 * 64
+    assert off.value == ((t0_floats + 63) // 64 * 64) * 4                                    # cat1 follows t0 in the arena
+    assert L.cid_stage_view(b"bottleneck", 2, 13, 18, *args) == 0 and (c.value, hs.value, ws.value, ps.value, co.value) == (256, 3, 4, 256, 0)
+    assert L.cid_stage_view(b"up1", 2, 13, 18, *args) == 0 and (c.value, co.value) == (64, 0)
+    assert L.cid_stage_view(b"upconv1", 2, 13, 18, *args) == 3                               # fused into the last kernel: never stored
+    assert L.cid_stage_view(b"down1", 1, 3, 3, *args) == 2
+    h = ctypes.c_void_p()
+    assert L.cid_create(ctypes.byref(h)) == 0
+    f, b, fe, be = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    algo = ctypes.c_int()
+    assert L.cid_get_tail_algo(h, ctypes.byref(algo)) == 0 and algo.value == _lib.CID_TAIL_FUSED
+    tot = {}
+    for mode in (_lib.CID_TAIL_FUSED, _lib.CID_TAIL_BANDS):
+        assert L.cid_set_tail_algo(h, mode) == 0
+        tot[mode] = [0.0, 0.0]
+        for i in range(12):
+            assert L.cid_launch_work_ex(h, i, 256, 128, 128, ctypes.byref(fe), ctypes.byref(be)) == 0
+            assert L.cid_launch_work(i, 256, 128, 128, ctypes.byref(f), ctypes.byref(b)) == 0
+            if mode == _lib.CID_TAIL_BANDS or i < 10:
+                assert (fe.value, be.value) == (f.value, b.value)
+            tot[mode][0] += fe.value
+            tot[mode][1] += be.value
+            if mode == _lib.CID_TAIL_FUSED and i == 11:
+                assert fe.value == 0.0 and be.value == 4.0 * (256 * 128 * 128 * 30 + 3)    # 27 z planes in, 3 channels out, bias
+    assert tot[_lib.CID_TAIL_FUSED][0] == tot[_lib.CID_TAIL_BANDS][0] == 256 * 11521753088.0
+    px = 256 * 128 * 128
+    assert tot[_lib.CID_TAIL_BANDS][1] - tot[_lib.CID_TAIL_FUSED][1] == 4.0 * px * 2 * (64 - 27)   # the 64-channel tensor never exists
+    assert L.cid_set_tail_algo(h, 7) == 1
+    assert L.cid_set_conv_algo(h, 1) == 1 and b"unknown algorithm" in L.cid_last_error(h)   # round 1's first Winograd kernel is gone
+    L.cid_destroy(h)
+
+
 def test_weight_staging_roundtrip_and_errors():
     L = _lib.lib()
     h = ctypes.c_void_p()
