@@ -200,6 +200,18 @@ def main():
                     help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
+    # Everything but the final JSON line goes to stderr: RCCL prints a version banner on stdout when its first communicator is
+    # created, and the contract is ONE line on stdout.  File descriptor 1 is pointed at stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -295,7 +307,7 @@ def main():
         except Exception as e:  # pragma: no cover
             res["parity"] = {"error": str(e)[:200]}
         if args.no_extras:
-            print(json.dumps(res))
+            emit(res)
             if use_dist:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -367,7 +379,7 @@ def main():
                 res["configs"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
-        print(json.dumps(res))
+        emit(res)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
