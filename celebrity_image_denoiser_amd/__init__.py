@@ -8,6 +8,7 @@ Public surface (mirrors what the reference's callers use, reference backend/app.
     denoise_u8(model, uint8 NHWC) -> uint8 NHWC (pre/post-processing fused into the first/last kernel)
     HostPipeline(model).run(host_batches)   upload / forward / download overlapped on three HIP streams
     GraphedForward(model, example)(x)       the forward at a fixed shape as one HIP-graph launch (N=1 serving latency)
+    enhance_images(ckpt, in_dir, out_dir)   the reference's directory eval harnesses (denoisegan_eval.py / denoise_eavl_iter.py)
 
 Everything numeric runs in hand-written HIP kernels behind the C ABI in include/cid.h
 (csrc/ -> libcid.so).  There is no CPU fallback: if the library is missing the calls raise.
@@ -26,6 +27,7 @@ _LAZY = {
     "HostPipeline": ("pipeline", "HostPipeline"),
     "denoise_host_batches": ("pipeline", "denoise_host_batches"),
     "GraphedForward": ("pipeline", "GraphedForward"),
+    "enhance_images": ("harness", "enhance_images"),
 }
 
 

@@ -260,6 +260,52 @@ def test_load_checkpoint_by_path_and_run(tmp_path, golden_dir, weight_sets):
         cid.load(os.path.join(tmp_path, "short.pth"), device="cuda:0", strict=True)
 
 
+def test_directory_harness_like_the_reference_eval_scripts(tmp_path, weight_sets):
+    """`enhance_images` = the reference's denoisegan_eval.py:62-103 / denoise_eavl_iter.py:62-114 loop on the GPU pipeline:
+    PNG/JPEG files in, bicubic resize (PIL, as in the reference), network, `*0.5+0.5`, ToPILImage truncation, files out
+    under the reference's names.  Checked against the CPU oracle fed with the same PIL-resized images."""
+    _need_gpu()
+    from PIL import Image
+
+    import celebrity_image_denoiser_amd as cid
+    from oracle import torch_oracle
+
+    src, dst, dst3 = tmp_path / "testNoise", tmp_path / "testOp", tmp_path / "testOp3"
+    src.mkdir()
+    _, _, noisy = synth.make_batch(5, 40, 52, first_index=8000)
+    for k in range(5):
+        Image.fromarray(noisy[k]).save(src / f"img{k}.{'png' if k % 2 == 0 else 'jpg'}")
+    (src / "notes.txt").write_text("not an image")
+    (src / "broken.png").write_bytes(b"not a png")
+    ckpt = tmp_path / "denoise_epoch_499.pth"
+    torch.save({"generator": {k: torch.from_numpy(v) for k, v in weight_sets["hot"].items()}, "epoch": 499}, ckpt)
+
+    written = cid.enhance_images(str(ckpt), str(src), str(dst), image_size=(32, 48), batch_size=3)
+    assert sorted(os.path.basename(p) for p in written) == [f"img{k}.{'png' if k % 2 == 0 else 'jpg'}" for k in range(5)]
+    for k in (0, 2, 4):   # PNG outputs are lossless: compare with the oracle on the same resized input
+        with Image.open(src / f"img{k}.png") as im:
+            x_u8 = np.asarray(im.convert("RGB").resize((32, 48), resample=Image.Resampling.BICUBIC))
+        ref = torch_oracle.forward(weight_sets["hot"], synth.normalize_u8(x_u8[None]))
+        ref_u8 = (ref * 0.5 + 0.5).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).numpy()[0]
+        got = np.asarray(Image.open(dst / f"img{k}.png"))
+        d = np.abs(got.astype(np.int16) - ref_u8.astype(np.int16))
+        assert got.shape == (48, 32, 3) and d.max() <= 1 and (d != 0).mean() <= 2e-3
+    # iterated variant: <base>_iter<i><ext> and <base>_final<ext>, three passes on the device
+    m = cid.load(str(ckpt), device="cuda:0", strict=True)
+    written3 = cid.enhance_images(None, str(src), str(dst3), image_size=(32, 48), num_iterations=3, model=m)
+    assert len(written3) == 5 * 4 and os.path.exists(dst3 / "img0_iter1.png") and os.path.exists(dst3 / "img0_final.png")
+    assert np.array_equal(np.asarray(Image.open(dst3 / "img0_iter3.png")), np.asarray(Image.open(dst3 / "img0_final.png")))
+    assert np.array_equal(np.asarray(Image.open(dst3 / "img0_iter1.png")), np.asarray(Image.open(dst / "img0.png")))
+    with Image.open(src / "img0.png") as im:
+        x_u8 = np.asarray(im.convert("RGB").resize((32, 48), resample=Image.Resampling.BICUBIC))
+    z = torch.from_numpy(synth.normalize_u8(x_u8[None]))
+    for _ in range(3):
+        z = torch_oracle.forward(weight_sets["hot"], z)
+    ref_u8 = (z * 0.5 + 0.5).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).numpy()[0]
+    d = np.abs(np.asarray(Image.open(dst3 / "img0_final.png")).astype(np.int16) - ref_u8.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
 def test_host_roundtrip_and_batch_split(models):
     import celebrity_image_denoiser_amd as cid
 
