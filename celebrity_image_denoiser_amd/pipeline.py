@@ -194,6 +194,9 @@ class GraphedForward:
         self._sig = model._packed_sig
         shape = self.static_in.shape
         n, h, w = (shape[0], shape[1], shape[2]) if self.u8 else (shape[0], shape[2], shape[3])
+        if model._needs_stripes(h, w):
+            raise RuntimeError("GraphedForward: images beyond the single-call size limit run as several striped forwards "
+                               "with intermediate allocations; call the model directly")
         shared, model._ws = model._ws, None
         try:
             model._ensure_arena(n, h, w, dev)

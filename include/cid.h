@@ -194,7 +194,8 @@ int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops
  * Where the output of one of the reference module's stages lives in the workspace of an [N,3,H,W] forward (NHWC,
  * fp32 — or half elements from the same base when the compute dtype is CID_DTYPE_F16).  `stage` is the attribute name of
  * the reference module whose forward-hook output it is (backend/app.py:42-78): "down1", "pool1", "down2", "pool2",
- * "bottleneck", "up2", "upconv2", "up1".  Element (n, y, x, c) of the stage is at
+ * "bottleneck", "up2", "upconv2", "up1", plus "upconv1.0" (upconv1[0] after its ReLU: the last layer's input; with
+ * CID_TAIL_FUSED that region holds the 27 planes z[N,27,Hs,Ws] instead and the view does not apply).  Element (n, y, x, c) of the stage is at
  *     offset_bytes/elem_size + ((n*Hs + y)*Ws + x)*pixel_stride + channel_offset + c        for y < Hs, x < Ws, c < C.
  * Skip tensors ("down1", "down2") are stored only over the region the concat keeps (top-left crop, app.py:90-92,97-99).
  * "upconv1" (pre-tanh) is never stored: it is fused into the last kernel.  Testing aid for per-stage parity.
