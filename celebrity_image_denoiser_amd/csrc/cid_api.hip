@@ -63,7 +63,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], h16_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -85,6 +85,10 @@ struct BlobLayout {
         }
         tab_off[0] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
         tab_off[1] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
+        for (int l = 0; l < NL; ++l) {   // fp16-storage path, 3x3 layers again in the fragment order of v_mfma_f32_16x16x32_f16
+            h16_off[l] = o;
+            if (kLayers[l].kind == CONV) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
+        }
         total = o;
     }
 };
@@ -156,6 +160,15 @@ size_t packed_index_h(const LayerDef& L, int co, int ci, int kh, int kw) {
     const int ck = ci >> 5, ks = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
     const int nchunk = L.cin / 32;
     return (((((size_t)(nb * nchunk + ck) * taps + tap) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
+}
+
+// k_conv3x3_h16: [nb][32-ch chunk][tap][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
+// lane (col, kg) of v_mfma_f32_16x16x32_f16 holds B[k = 8kg..8kg+7][col].
+size_t packed_index_h16(const LayerDef& L, int co, int ci, int kh, int kw) {
+    const int tap = kh * 3 + kw, nb = co >> 6, cg = (co >> 4) & 3, c = co & 15;
+    const int ck = ci >> 5, kg = (ci >> 3) & 3, e = ci & 7;
+    const int nchunk = L.cin / 32;
+    return (((((size_t)(nb * nchunk + ck) * 9 + tap) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
 }
 
 struct Dims {
@@ -389,7 +402,11 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     if constexpr (MODE == 2) hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    else if (getenv("CID_F16_32X32")) hipLaunchKernelGGL((k_conv3x3_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    else {
+        a.w = reinterpret_cast<const _Float16*>(blob + kBlob.h16_off[layer]);
+        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -547,6 +564,10 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
+        }
+        if (L.kind == CONV) {
+            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h16_off[l]);
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h16(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
         }
     }
     h->have[l][is_bias] = true;

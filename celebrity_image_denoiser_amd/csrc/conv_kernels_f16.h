@@ -389,6 +389,174 @@ __global__ void __launch_bounds__(THREADS, MODE == 0 ? 4 : 3) k_conv3x3_h(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 layers of the fp16-storage path, third form: v_mfma_f32_16x16x32_f16.
+//
+// The fp16 forward runs at the board's power cap, so what counts is energy per FLOP.  On random,
+// LDS-fed operands the 16x16x32 shape sustains 1.93 PFLOP/s where 32x32x16 sustains 1.58 (tools/mfma_shape_probe: same
+// FLOPs and LDS bytes per step; a 32x32 tile rewrites 16 accumulator registers per instruction, a 16x16 tile 4 for half the
+// FLOPs).  Same workgroup tile as before (8x32 pixels x 64 channels, wave = 2 rows), 32-channel chunks:
+//   * wave tile = 4 pixel groups (2 rows x 2 halves of 16) x 4 channel groups of 16 -> 16 accumulator tiles of 4 registers;
+//     per tap: 4 A + 4 B fragments (ds_read_b128 each), 16 MFMAs;
+//   * A: lane (pixel = l & 15, k-group = l >> 4) takes channels 8kg..8kg+7 -> the halo tile lies in LDS as four planes
+//     [k-group][352 pixel slots] of 16-byte quads: the 16 lanes of a ds_read_b128 service group are 16 consecutive pixels of one
+//     or two planes whose stride is a multiple of 16 slots -> conflict-free, every (tap, row, half) address an immediate;
+//   * B: packed on the host per lane, [chunk][tap][channel group][lane = 16 kg + col][8] (cid_api.hip packed_index_h16),
+//     through LDS once per workgroup as in k_conv3x3_h.
+template <int CIN, int COUT, int MODE>
+__global__ void __launch_bounds__(THREADS, 2) k_conv3x3_h16(const GemmConvArgsH a) {
+    static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
+    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
+    constexpr int PLANE = (LPIX + 15) / 16 * 16;                          // 352 slots per k-group plane
+    constexpr int NSLOT = LPIX * 4, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6
+    constexpr int NCHUNK = CIN / 32;
+    constexpr int NB = COUT / NTILE;
+    constexpr int BSLOTS = 9 * 4 * 64, NBL = BSLOTS / THREADS;            // 2304 quads of B per chunk, 9 per thread
+    constexpr int HALO_SLOTS = 4 * PLANE;
+    constexpr int LDS_SLOTS = HALO_SLOTS + BSLOTS;                        // 59,392 B (store staging reuses it)
+    static_assert(LDS_SLOTS * 16 >= 4 * WS_FLOATS * 4, "staging must fit");
+    __shared__ f32x4 lds[LDS_SLOTS];
+
+    int mt, nb;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    int n, ty, tx;
+    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
+    const int cobase = nb * NTILE;
+    float bias_v[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16];
+
+    // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot (s & 3) * PLANE + (s >> 2)
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * a.Hin * a.Win * a.in_ps), (short)0,
+                                                                             a.Hin * a.Win * a.in_ps * 2, 0x00020000);
+    unsigned goff[NLOAD];
+    int hslot[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+        const int sidx = it * THREADS + tid;
+        const int p = sidx >> 2, q = sidx & 3;
+        const int hy = p / LW, hx = p - hy * LW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = sidx < NSLOT && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
+        hslot[it] = sidx < NSLOT ? q * PLANE + p : -1;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
+    const int wbase = nb * NCHUNK * BSLOTS * 16;
+    f32x4* const ldsb = lds + HALO_SLOTS;
+    f32x4 pre[NLOAD], bpre[NBL];
+    auto request = [&](int ck) {
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * 64, 0));
+#pragma unroll
+        for (int j = 0; j < NBL; ++j)
+            bpre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase + ck * (BSLOTS * 16) + j * 4096, 0));
+    };
+    auto stage_to_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it)
+            if (hslot[it] >= 0) lds[hslot[it]] = pre[it];
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
+    };
+    request(0);
+    stage_to_lds();
+    __syncthreads();
+
+    const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
+    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;     // B quad (tap, cg) of this lane at [(4 tap + cg) * 64]
+    const int abase = kg * PLANE + (2 * wave) * LW + c16;                 // pixel (row 2*wave, column c16) of plane kg, tap (0,0)
+    f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
+    auto load_frags = [&](int tap, f16x8 (&af)[2][2], f16x8 (&bf)[4]) {
+        const int off = (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) af[m][pg] = ldsh[abase + off + m * LW + pg * 16];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) bf[cg] = ldsbh[(4 * tap + cg) * 64];
+    };
+    auto chunk = [&](auto first_tag, auto pref_tag, int ck) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool PREF = decltype(pref_tag)::value;
+        f16x8 af[2][2][2], bf[2][4];                                      // double-buffered fragments (static indices: the tap loop is unrolled)
+        load_frags(0, af[0], bf[0]);
+        if (PREF) request(ck + 1);                                        // the whole next chunk, before this chunk's first MFMA
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) load_frags(tap + 1, af[(tap + 1) & 1], bf[(tap + 1) & 1]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        if (FIRST && tap == 0) {
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[tap & 1][m][pg], bf[tap & 1][cg], zero, 0, 0, 0);
+                        } else {
+                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[tap & 1][m][pg], bf[tap & 1][cg], acc[m][pg][cg], 0, 0, 0);
+                        }
+                    }
+        }
+        if (PREF) {
+            __syncthreads();
+            stage_to_lds();
+            __syncthreads();
+        }
+    };
+    static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
+    chunk(std::true_type{}, std::true_type{}, 0);
+    for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
+    chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
+
+    // ---- epilogue: lane (channel c16 of group cg, row group kg) holds pixels 16 pg + 4 kg + r (r = 0..3) of its two rows ----
+    // staged per wave as [32 pixels][64 channels] fp32 (the layout wide_store_h reads), one row at a time
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    auto store_row = [&](auto value, auto npix_tag, _Float16* base, int stride, int xlim, bool rowok, bool full) {
+        // value(pg, cg, r) -> fp32 of pixel 16 pg + 4 kg + r (npix = 32) or pooled pixel 8 pg + 2 kg + r (npix = 16, r = 0..1)
+        constexpr int npix = decltype(npix_tag)::value, per = npix == 32 ? 4 : 2;
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int r = 0; r < per; ++r)
+                    stg[((npix / 2) * pg + per * kg + r) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
+        wave_lds_fence();
+        for (int it = 0; it < npix / 8; ++it) {
+            const int px = it * 8 + (lane >> 3);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
+            if (full || (rowok && px < xlim)) *reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8) = v;
+        }
+        wave_lds_fence();
+    };
+    const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0) * a.out_ps + a.out_coff + cobase;
+        store_row([&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, std::integral_constant<int, 32>{}, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
+    }
+    if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
+        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        const int py = (y0 >> 1) + wave;
+        _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp + (x0 >> 1)) * COUT + cobase;
+        store_row([&](int pg, int cg, int r) {
+                      const float v = fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1]));
+                      return fmaxf(v + bias_v[cg], 0.f);
+                  },
+                  std::integral_constant<int, 16>{}, prow, COUT, Wp - (x0 >> 1), py < Hp, false);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tail of the fp16-storage path: upconv1[2] + tanh (app.py:77,101,103) on a half NHWC input.  Same algorithm as
 // k_conv_tail (z = x . W for every halo pixel as a [352 x 64] x [64 x 32] product, then the nine shifted sums), but the
 // product runs on v_mfma_f32_32x32x16_f16 straight from the half tile: 4 MFMAs per 32 pixels instead of 32, no
