@@ -162,13 +162,13 @@ size_t packed_index_h(const LayerDef& L, int co, int ci, int kh, int kw) {
     return (((((size_t)(nb * nchunk + ck) * taps + tap) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
 }
 
-// k_conv3x3_h16: [nb][32-ch chunk][tap][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
-// lane (col, kg) of v_mfma_f32_16x16x32_f16 holds B[k = 8kg..8kg+7][col].
+// k_conv3x3_h16: [nb][32-ch chunk][dx][dy][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
+// lane (col, kg) of v_mfma_f32_16x16x32_f16 holds B[k = 8kg..8kg+7][col]; one (chunk, dx) is a 12 KiB LDS-DMA unit.
 size_t packed_index_h16(const LayerDef& L, int co, int ci, int kh, int kw) {
-    const int tap = kh * 3 + kw, nb = co >> 6, cg = (co >> 4) & 3, c = co & 15;
+    const int nb = co >> 6, cg = (co >> 4) & 3, c = co & 15;
     const int ck = ci >> 5, kg = (ci >> 3) & 3, e = ci & 7;
     const int nchunk = L.cin / 32;
-    return (((((size_t)(nb * nchunk + ck) * 9 + tap) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
+    return ((((((size_t)(nb * nchunk + ck) * 3 + kw) * 3 + kh) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
 }
 
 struct Dims {

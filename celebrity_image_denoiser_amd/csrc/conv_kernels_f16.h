@@ -400,19 +400,21 @@ __global__ void __launch_bounds__(THREADS, MODE == 0 ? 4 : 3) k_conv3x3_h(const 
 //   * A: lane (pixel = l & 15, k-group = l >> 4) takes channels 8kg..8kg+7 -> the halo tile lies in LDS as four planes
 //     [k-group][352 pixel slots] of 16-byte quads: the 16 lanes of a ds_read_b128 service group are 16 consecutive pixels of one
 //     or two planes whose stride is a multiple of 16 slots -> conflict-free, every (tap, row, half) address an immediate;
-//   * B: packed on the host per lane, [chunk][tap][channel group][lane = 16 kg + col][8] (cid_api.hip packed_index_h16),
-//     through LDS once per workgroup as in k_conv3x3_h.
+//   * B: packed on the host per lane, [chunk][dx][dy][channel group][lane = 16 kg + col][8] (cid_api.hip packed_index_h16);
+//     one tap column (12 KiB) at a time by LDS-DMA into one of two buffers — no staging registers, and the LDS stays under a
+//     third of the CU's; the halo tile of the next chunk waits in 24 registers over the chunk's last sub-step;
+//   * per sub-step the wave reads its four input rows once (8 A quads) and 12 B quads for 48 MFMAs.
 template <int CIN, int COUT, int MODE>
-__global__ void __launch_bounds__(THREADS, 2) k_conv3x3_h16(const GemmConvArgsH a) {
+__global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
     constexpr int PLANE = (LPIX + 15) / 16 * 16;                          // 352 slots per k-group plane
     constexpr int NSLOT = LPIX * 4, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6
-    constexpr int NCHUNK = CIN / 32;
+    constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * 3;
     constexpr int NB = COUT / NTILE;
-    constexpr int BSLOTS = 9 * 4 * 64, NBL = BSLOTS / THREADS;            // 2304 quads of B per chunk, 9 per thread
+    constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     constexpr int HALO_SLOTS = 4 * PLANE;
-    constexpr int LDS_SLOTS = HALO_SLOTS + BSLOTS;                        // 59,392 B (store staging reuses it)
+    constexpr int LDS_SLOTS = HALO_SLOTS + 2 * BSUB;                      // 47,104 B -> three workgroups per CU
     static_assert(LDS_SLOTS * 16 >= 4 * WS_FLOATS * 4, "staging must fit");
     __shared__ f32x4 lds[LDS_SLOTS];
 
@@ -423,15 +425,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv3x3_h16(const GemmConvArgsH 
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
     const int cobase = nb * NTILE;
-    float bias_v[4];
-#pragma unroll
-    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16];
 
-    // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot (s & 3) * PLANE + (s >> 2)
+    // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot (tid & 3) * PLANE + (tid >> 2) + 64 it
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * a.Hin * a.Win * a.in_ps), (short)0,
                                                                              a.Hin * a.Win * a.in_ps * 2, 0x00020000);
     unsigned goff[NLOAD];
-    int hslot[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
         const int sidx = it * THREADS + tid;
@@ -440,76 +438,107 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv3x3_h16(const GemmConvArgsH 
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = sidx < NSLOT && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
         goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
-        hslot[it] = sidx < NSLOT ? q * PLANE + p : -1;
     }
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
-    const int wbase = nb * NCHUNK * BSLOTS * 16;
-    f32x4* const ldsb = lds + HALO_SLOTS;
-    f32x4 pre[NLOAD], bpre[NBL];
-    auto request = [&](int ck) {
+    const int hbase = (tid & 3) * PLANE + (tid >> 2);
+    f32x4 pre[NLOAD];
+    auto request_halo = [&](int ck) {
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * 64, 0));
-#pragma unroll
-        for (int j = 0; j < NBL; ++j)
-            bpre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase + ck * (BSLOTS * 16) + j * 4096, 0));
     };
-    auto stage_to_lds = [&]() {
+    auto halo_to_lds = [&]() {
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
-            if (hslot[it] >= 0) lds[hslot[it]] = pre[it];
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
+            if (it * THREADS + tid < NSLOT) lds[hbase + it * 64] = pre[it];
     };
-    request(0);
-    stage_to_lds();
+    // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
+    const int wbase = nb * NSUB * (BSUB * 16);
+    const unsigned lds_b = (unsigned)(uintptr_t)(&lds[HALO_SLOTS]);
+    const unsigned vlane = lane * 16;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_b = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned dst = lds_b + (unsigned)((((g & 1) * BSUB) + (wave_s + 4 * j) * 64) * 16);
+            const int soff = wbase + g * (BSUB * 16) + (wave_s + 4 * j) * 1024;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vlane), "s"(rsrc_w), "s"(dst), "s"(soff) : "memory");
+        }
+    };
+    dma_b(0);
+    request_halo(0);
+    float bias_v[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16];
+    halo_to_lds();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to hipcc's own wait counting
     __syncthreads();
 
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
-    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;     // B quad (tap, cg) of this lane at [(4 tap + cg) * 64]
-    const int abase = kg * PLANE + (2 * wave) * LW + c16;                 // pixel (row 2*wave, column c16) of plane kg, tap (0,0)
+    const int abase = kg * PLANE + (2 * wave) * LW + c16;                 // pixel (row 2*wave, column c16) of plane kg
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
-    auto load_frags = [&](int tap, f16x8 (&af)[2][2], f16x8 (&bf)[4]) {
-        const int off = (tap / 3) * LW + (tap % 3);
+    // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
+    auto substep = [&](auto first_tag, auto last_tag, int g, int dx) {
+        constexpr bool FIRST = decltype(first_tag)::value;    // very first sub-step: the accumulators start from zero
+        constexpr bool LAST = decltype(last_tag)::value;      // very last: nothing more to fetch
+        const f16x8* bq = ldsh + HALO_SLOTS + (g & 1) * BSUB + lane;
+        const f16x8* aq = ldsh + abase + dx;
+        if (!LAST) dma_b(g + 1);
+        f16x8 ar[4][2], bf[3][4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int cg = 0; cg < 4; ++cg) bf[0][cg] = bq[cg * 64];
 #pragma unroll
-            for (int pg = 0; pg < 2; ++pg) af[m][pg] = ldsh[abase + off + m * LW + pg * 16];
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) bf[cg] = ldsbh[(4 * tap + cg) * 64];
-    };
-    auto chunk = [&](auto first_tag, auto pref_tag, int ck) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr bool PREF = decltype(pref_tag)::value;
-        f16x8 af[2][2][2], bf[2][4];                                      // double-buffered fragments (static indices: the tap loop is unrolled)
-        load_frags(0, af[0], bf[0]);
-        if (PREF) request(ck + 1);                                        // the whole next chunk, before this chunk's first MFMA
+            for (int pg = 0; pg < 2; ++pg) ar[r][pg] = aq[r * LW + pg * 16];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) load_frags(tap + 1, af[(tap + 1) & 1], bf[(tap + 1) & 1]);
+        for (int dy = 0; dy < 3; ++dy) {
+            if (dy < 2) {
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg) ar[dy + 2][pg] = aq[(dy + 2) * LW + pg * 16];
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) bf[dy + 1][cg] = bq[((dy + 1) * 4 + cg) * 64];
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
                     for (int cg = 0; cg < 4; ++cg) {
-                        if (FIRST && tap == 0) {
+                        if (FIRST && dy == 0) {
                             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[tap & 1][m][pg], bf[tap & 1][cg], zero, 0, 0, 0);
+                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], zero, 0, 0, 0);
                         } else {
-                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[tap & 1][m][pg], bf[tap & 1][cg], acc[m][pg][cg], 0, 0, 0);
+                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], acc[m][pg][cg], 0, 0, 0);
                         }
                     }
         }
-        if (PREF) {
-            __syncthreads();
-            stage_to_lds();
-            __syncthreads();
-        }
+    };
+    auto seam = [&]() {   // between sub-steps of one chunk: the next B sub-chunk has landed in every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto chunk_seam = [&]() {   // between chunks: the halo tile is replaced as well
+        __syncthreads();
+        halo_to_lds();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
     static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
-    chunk(std::true_type{}, std::true_type{}, 0);
-    for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
-    chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
+    using T = std::true_type;
+    using F = std::false_type;
+    substep(T{}, F{}, 0, 0); seam();
+    substep(F{}, F{}, 1, 1); seam();
+    request_halo(1);
+    substep(F{}, F{}, 2, 2); chunk_seam();
+    for (int ck = 1; ck + 1 < NCHUNK; ++ck) {
+        substep(F{}, F{}, 3 * ck, 0); seam();
+        substep(F{}, F{}, 3 * ck + 1, 1); seam();
+        request_halo(ck + 1);
+        substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam();
+    }
+    substep(F{}, F{}, NSUB - 3, 0); seam();
+    substep(F{}, F{}, NSUB - 2, 1); seam();
+    substep(F{}, T{}, NSUB - 1, 2);
 
     // ---- epilogue: lane (channel c16 of group cg, row group kg) holds pixels 16 pg + 4 kg + r (r = 0..3) of its two rows ----
     // staged per wave as [32 pixels][64 channels] fp32 (the layout wide_store_h reads), one row at a time
