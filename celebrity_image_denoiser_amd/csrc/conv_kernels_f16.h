@@ -408,7 +408,8 @@ template <int CIN, int COUT, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
-    constexpr int PLANE = (LPIX + 15) / 16 * 16;                          // 352 slots per k-group plane
+    constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see below
+    static_assert(PLANE % 16 == 4, "the fragment row permutation below assumes plane stride = 4 mod 16");
     constexpr int NSLOT = LPIX * 4, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6
     constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * 3;
     constexpr int NB = COUT / NTILE;
@@ -474,7 +475,12 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     __syncthreads();
 
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
-    const int abase = kg * PLANE + (2 * wave) * LW + c16;                 // pixel (row 2*wave, column c16) of plane kg
+    // MFMA row i of a 16-pixel group is pixel prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1): with the planes 4 (mod 16) slots
+    // apart, the two k-groups that share a ds_read_b128 service group ({0-3,12-15} of one, {4-11} of the next) then cover 16
+    // different slots (mod 16), and the halo stores (4 k-groups x 2 pixels per 8-lane group) are 2-way instead of 4-way.
+    // Horizontal neighbours (2j, 2j+1) stay in one lane's four rows, which the pooled epilogue needs.
+    const int prow = ((0xa802 >> (4 * (c16 >> 2))) & 15) + (c16 & 1) + 2 * (c16 & 2);
+    const int abase = kg * PLANE + (2 * wave) * LW + prow;                // pixel (row 2*wave, column prow) of plane kg
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
     auto substep = [&](auto first_tag, auto last_tag, int g, int dx) {
@@ -540,12 +546,13 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     substep(F{}, F{}, NSUB - 2, 1); seam();
     substep(F{}, T{}, NSUB - 1, 2);
 
-    // ---- epilogue: lane (channel c16 of group cg, row group kg) holds pixels 16 pg + 4 kg + r (r = 0..3) of its two rows ----
+    // ---- epilogue: lane (channel c16 of group cg, row group kg) holds pixels 16 pg + {2,0,8,10}[kg] + (r&1) + 4(r>>1) of its two rows ----
     // staged per wave as [32 pixels][64 channels] fp32 (the layout wide_store_h reads), one row at a time
     __syncthreads();
     float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    const int pb = (0xa802 >> (4 * kg)) & 15;
     auto store_row = [&](auto value, auto npix_tag, _Float16* base, int stride, int xlim, bool rowok, bool full) {
-        // value(pg, cg, r) -> fp32 of pixel 16 pg + 4 kg + r (npix = 32) or pooled pixel 8 pg + 2 kg + r (npix = 16, r = 0..1)
+        // value(pg, cg, r) -> fp32 of pixel 16 pg + pb + (r&1) + 4(r>>1) (npix = 32) or pooled pixel 8 pg + pb/2 + 2r (npix = 16, r = 0..1)
         constexpr int npix = decltype(npix_tag)::value, per = npix == 32 ? 4 : 2;
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg)
@@ -553,7 +560,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
                 for (int r = 0; r < per; ++r)
-                    stg[((npix / 2) * pg + per * kg + r) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
+                    stg[((npix / 2) * pg + (npix == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r)) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
         wave_lds_fence();
         for (int it = 0; it < npix / 8; ++it) {
             const int px = it * 8 + (lane >> 3);
