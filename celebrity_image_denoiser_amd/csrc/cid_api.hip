@@ -63,7 +63,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], h16_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], h16_off[NL], head16_off, raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -89,6 +89,7 @@ struct BlobLayout {
             h16_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
         }
+        head16_off = o; o = align_up(o + 4 * 64 * 8 / 2, 64);   // k_conv_head_h16: [cg][lane][8] halfs
         total = o;
     }
 };
@@ -368,9 +369,9 @@ hipError_t launch_layer(cid_handle_t h, hipStream_t s, const float* blob, int la
 }
 
 hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8, bool f16) {
-    if (u8 && f16) hipLaunchKernelGGL((k_conv_head<true, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    if (u8 && f16) hipLaunchKernelGGL((k_conv_head_h16<true>), dim3(grid), dim3(THREADS), 0, s, a);
     else if (u8) hipLaunchKernelGGL((k_conv_head<true, false>), dim3(grid), dim3(THREADS), 0, s, a);
-    else if (f16) hipLaunchKernelGGL((k_conv_head<false, true>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (f16) hipLaunchKernelGGL((k_conv_head_h16<false>), dim3(grid), dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_conv_head<false, false>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
@@ -445,7 +446,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
 
     {   // down1[0]: Conv 3->64 + ReLU, NCHW in -> NHWC t0            app.py:43-44
         HeadArgs a;
-        a.in = in; a.w = blob + kBlob.w_off[0]; a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
+        a.in = in; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.head16_off : kBlob.w_off[0]); a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
@@ -564,6 +565,15 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
+        }
+        if (l == 0) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = co % 16, kg) of group co / 16 holds k = 8kg..8kg+7
+            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.head16_off);
+            for (int co = 0; co < 64; ++co)
+                for (int k = 0; k < 32; ++k) {
+                    const int tap = k / 3, c = k % 3;
+                    const float v = k < 27 ? data[ref_index(L, co, c, tap / 3, tap % 3)] : 0.f;
+                    hd[((co >> 4) * 64 + (k >> 3) * 16 + (co & 15)) * 8 + (k & 7)] = (_Float16)v;
+                }
         }
         if (L.kind == CONV) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h16_off[l]);

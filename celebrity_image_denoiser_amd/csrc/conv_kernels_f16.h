@@ -388,6 +388,61 @@ __global__ void __launch_bounds__(THREADS, MODE == 0 ? 4 : 3) k_conv3x3_h(const 
     gemm_h_epilogue<COUT, MODE>(a, lds, acc, bias_v, n, y0, x0, wave, lane, h, 0, cobase);
 }
 
+// Row permutation of the 16x16x32 kernels: MFMA row i of a 16-pixel group is pixel h16_prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1).
+__device__ __forceinline__ int h16_prow(int i) { return ((0xa802 >> (4 * (i >> 2))) & 15) + (i & 1) + 2 * (i & 2); }
+
+// Stores of the 16x16x32 kernels.  In an accumulator tile, lane (channel c16 = lane & 15 of group cg, row group kg = lane >> 4) holds
+// pixels 16 pg + {2,0,8,10}[kg] + (r&1) + 4(r>>1) (r = 0..3) of one output row.  h16_store_row stages NPIX = 32 such pixels (or the
+// NPIX = 16 pooled ones, 8 pg + {1,0,4,5}[kg] + 2r, r = 0..1) x 64 channels as fp32 in `stg` (WS_FLOATS floats, wave-private: no
+// workgroup barrier inside), rounds once to half and writes 16 bytes per lane.  value(pg, cg, r) yields the finished fp32 element.
+template <int NPIX, typename V>
+__device__ __forceinline__ void h16_store_row(float* stg, int lane, V value, _Float16* base, int stride, int xlim, bool rowok, bool full) {
+    constexpr int per = NPIX == 32 ? 4 : 2;
+    const int c16 = lane & 15, pb = (0xa802 >> (4 * (lane >> 4))) & 15;
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int r = 0; r < per; ++r)
+                stg[((NPIX / 2) * pg + (NPIX == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r)) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
+    wave_lds_fence();
+    for (int it = 0; it < NPIX / 8; ++it) {
+        const int px = it * 8 + (lane >> 3);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
+        if (full || (rowok && px < xlim)) *reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8) = v;
+    }
+    wave_lds_fence();
+}
+
+// Epilogue of k_conv3x3_h16: bias + ReLU on the wave's two rows (+ the 2x2 max-pooled copy).
+template <int COUT, int MODE, typename Args>
+__device__ __forceinline__ void h16_epilogue(const Args& a, float* stg, f32x4 (&acc)[2][2][4], const float (&bias_v)[4], int n, int y0, int x0,
+                                             int wave, int lane, int cobase) {
+    const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0) * a.out_ps + a.out_coff + cobase;
+        h16_store_row<32>(stg, lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
+    }
+    if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
+        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        const int py = (y0 >> 1) + wave;
+        _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp + (x0 >> 1)) * COUT + cobase;
+        h16_store_row<16>(stg, lane,
+                          [&](int pg, int cg, int r) {
+                              const float v = fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1]));
+                              return fmaxf(v + bias_v[cg], 0.f);
+                          },
+                          prow, COUT, Wp - (x0 >> 1), py < Hp, false);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 layers of the fp16-storage path, third form: v_mfma_f32_16x16x32_f16.
 //
@@ -465,6 +520,10 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vlane), "s"(rsrc_w), "s"(dst), "s"(soff) : "memory");
         }
     };
+#ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 stamps s_memtime at the phase boundaries into a.pool, results unchanged
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8;
+    if (tid == 0) trace[0] = __builtin_readcyclecounter();
+#endif
     dma_b(0);
     request_halo(0);
     float bias_v[4];
@@ -474,12 +533,15 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to hipcc's own wait counting
     __syncthreads();
 
+#ifdef H16_TRACE
+    if (tid == 0) trace[1] = __builtin_readcyclecounter();
+#endif
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
     // MFMA row i of a 16-pixel group is pixel prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1): with the planes 4 (mod 16) slots
     // apart, the two k-groups that share a ds_read_b128 service group ({0-3,12-15} of one, {4-11} of the next) then cover 16
     // different slots (mod 16), and the halo stores (4 k-groups x 2 pixels per 8-lane group) are 2-way instead of 4-way.
     // Horizontal neighbours (2j, 2j+1) stay in one lane's four rows, which the pooled epilogue needs.
-    const int prow = ((0xa802 >> (4 * (c16 >> 2))) & 15) + (c16 & 1) + 2 * (c16 & 2);
+    const int prow = h16_prow(c16);
     const int abase = kg * PLANE + (2 * wave) * LW + prow;                // pixel (row 2*wave, column prow) of plane kg
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
@@ -546,49 +608,131 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     substep(F{}, F{}, NSUB - 2, 1); seam();
     substep(F{}, T{}, NSUB - 1, 2);
 
-    // ---- epilogue: lane (channel c16 of group cg, row group kg) holds pixels 16 pg + {2,0,8,10}[kg] + (r&1) + 4(r>>1) of its two rows ----
-    // staged per wave as [32 pixels][64 channels] fp32 (the layout wide_store_h reads), one row at a time
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
-    const int pb = (0xa802 >> (4 * kg)) & 15;
-    auto store_row = [&](auto value, auto npix_tag, _Float16* base, int stride, int xlim, bool rowok, bool full) {
-        // value(pg, cg, r) -> fp32 of pixel 16 pg + pb + (r&1) + 4(r>>1) (npix = 32) or pooled pixel 8 pg + pb/2 + 2r (npix = 16, r = 0..1)
-        constexpr int npix = decltype(npix_tag)::value, per = npix == 32 ? 4 : 2;
-#pragma unroll
-        for (int pg = 0; pg < 2; ++pg)
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-                for (int r = 0; r < per; ++r)
-                    stg[((npix / 2) * pg + (npix == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r)) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
-        wave_lds_fence();
-        for (int it = 0; it < npix / 8; ++it) {
-            const int px = it * 8 + (lane >> 3);
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
-            f16x8 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
-            if (full || (rowok && px < xlim)) *reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8) = v;
-        }
-        wave_lds_fence();
-    };
-    const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int y = y0 + 2 * wave + m;
-        _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0) * a.out_ps + a.out_coff + cobase;
-        store_row([&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, std::integral_constant<int, 32>{}, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
+#ifdef H16_TRACE
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
+    if (tid == 0) trace[2] = __builtin_readcyclecounter();
+#endif
+    __syncthreads();   // the store staging reuses the operand LDS
+    h16_epilogue<COUT, MODE>(a, reinterpret_cast<float*>(lds) + wave * WS_FLOATS, acc, bias_v, n, y0, x0, wave, lane, cobase);
+#ifdef H16_TRACE
+    if (tid == 0) {
+        trace[3] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace[4] = __builtin_readcyclecounter();
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[5] = hwid; trace[6] = xcc;
     }
-    if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
-        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-        const int py = (y0 >> 1) + wave;
-        _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp + (x0 >> 1)) * COUT + cobase;
-        store_row([&](int pg, int cg, int r) {
-                      const float v = fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1]));
-                      return fmaxf(v + bias_v[cg], 0.f);
-                  },
-                  std::integral_constant<int, 16>{}, prow, COUT, Wp - (x0 >> 1), py < Hp, false);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head of the fp16-storage path: down1[0] = Conv2d(3, 64, 3, padding=1) + ReLU (app.py:46-47) on v_mfma_f32_16x16x32_f16.
+// K = 3 channels x 9 taps = 27 fits ONE K = 32 step (k = 3 tap + c, rows 27..31 of the packed weights are zero), so a 16-pixel x
+// 16-channel tile is a single MFMA; the fp32-MFMA head needs 14 steps of 32x32x2 per 32 x 32 and was the one launch of the fp16 forward
+// still priced in fp32 MFMA time (0.365 ms for 512 images against 0.21 for its 1.07 GB of stores).  The image is rounded to half
+// here (as every later activation of this path is); accumulation stays fp32.
+//   * input: planar [3][10][36] halfs in LDS, filled like k_conv_head's (all loads of the NEXT tile in flight under this tile's work);
+//   * A: lane (pixel h16_prow(lane & 15), k-group kg) gathers its eight k = 8kg..8kg+7 with eight 2-byte LDS reads at lane-constant offsets;
+//   * B: [4 channel groups][lane][8] halfs, 16 registers for the whole kernel (host: pack_head_h16);
+//   * stores: h16_store_row (bias, ReLU, wave-private staging, 16-byte stores), one output row at a time.
+template <bool IN_U8>
+__global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) {
+    constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;
+    constexpr int IMG_BYTES = (3 * PLANE * 2 + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[IMG_BYTES + 4 * WS_FLOATS * 4];   // image | store staging (37.0 KB)
+    _Float16* const img_h = reinterpret_cast<_Float16*>(lds_raw);
+    int grp, nb;
+    if (!decode_block(a.groups_total, a.groups_per_xcd, 1, grp, nb)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
+    float* const stg = reinterpret_cast<float*>(lds_raw + IMG_BYTES) + wave * WS_FLOATS;
+
+    constexpr int NS = 3 * LH * 34, NIT = (NS + THREADS - 1) / THREADS;
+    const size_t img = (size_t)a.H * a.W * 3;   // elements per image in either input format
+    // element s = it*256 + tid of the [3][LH][34] halo patch: plane, row, column are recomputed per tile (a few integer operations
+    // against 12 registers held across the MFMAs: this kernel sits at the 128-register step)
+    auto patch = [&](int it, int& c, int& hy, int& hx) {
+        const int s = it * THREADS + tid;
+        c = s / (LH * 34);
+        const int rem = s - c * (LH * 34);
+        hy = rem / 34; hx = rem - hy * 34;
+        return s < NS;
+    };
+    float staged[NIT];
+    auto request_tile = [&](int tile, int& tn, int& ty0, int& tx0) {
+        int ty, tx;
+        decode_tile(tile, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, tn, ty, tx);
+        ty0 = ty * TILE_H; tx0 = tx * TILE_W;
+        const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+            IN_U8 ? (void*)(static_cast<const unsigned char*>(a.in) + (size_t)tn * img) : (void*)(static_cast<const float*>(a.in) + (size_t)tn * img),
+            (short)0, (int)(IN_U8 ? img : img * 4), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c, hy, hx;
+            const bool in_patch = patch(it, c, hy, hx);
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+            const bool ok = in_patch && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((gy * a.W + gx) * 3 + c) : (unsigned)(((c * a.H + gy) * a.W + gx) * 4);
+            if (IN_U8) {
+                // zero padding applies to the NORMALISED tensor: a padded element is 0, not (0/255 - 0.5)/0.5
+                const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_in, goff, 0, 0);
+                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : 0.f;
+            } else {
+                staged[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+            }
+        }
+    };
+    const int tile0 = grp * a.tiles_per_wg;
+    const int ntile = min(a.tiles_per_wg, a.tiles_total - tile0);   // >= 1 (decode_block), workgroup-uniform
+    int n, y0, x0;
+    request_tile(tile0, n, y0, x0);
+    f16x8 bfr[4];
+    float bias_v[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        bfr[cg] = reinterpret_cast<const f16x8*>(a.w)[cg * 64 + lane];
+        bias_v[cg] = a.bias[cg * 16 + c16];
+    }
+    int koff[8];   // k = 8 kg + e = 3 tap + c -> offset of (plane c, tap row, tap column); k >= 27 meets zero weights, any finite element will do
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = min(8 * kg + e, 26), tap = k / 3, c = k - 3 * tap;
+        koff[e] = c * PLANE + (tap / 3) * LW + (tap % 3);
+    }
+    const int pbase = (2 * wave) * LW + h16_prow(c16);
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c, hy, hx;
+            if (patch(it, c, hy, hx)) img_h[c * PLANE + hy * LW + hx] = (_Float16)staged[it];
+        }
+        __syncthreads();
+        int nn = n, ny0 = y0, nx0 = x0;
+        if (t + 1 < ntile) request_tile(tile0 + t + 1, nn, ny0, nx0);   // in flight under this tile's MFMAs and stores
+        const bool full = y0 + TILE_H <= a.H && x0 + TILE_W <= a.W;
+#pragma unroll 1
+        for (int m = 0; m < 2; ++m) {   // a row at a time: 32 accumulator registers, this kernel sits at the 128-register step
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                f16x8 af;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[e] = img_h[pbase + m * LW + pg * 16 + koff[e]];
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[cg], zero, 0, 0, 0);
+                }
+            }
+            const int y = y0 + 2 * wave + m;
+            _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W + x0) * 64;
+            h16_store_row<32>(stg, lane, [&](int pg, int cg, int r) { return fmaxf(acc[pg][cg][r] + bias_v[cg], 0.f); }, orow, 64, a.W - x0, y < a.H, full);
+        }
+        n = nn; y0 = ny0; x0 = nx0;
+        if (t + 1 < ntile) __syncthreads();   // every wave is done reading the planes before the next tile overwrites them
     }
 }
 
