@@ -36,9 +36,9 @@ const char* kKernelNames[NL] = {
 };
 
 const char* kHalfKernelNames[NL] = {
-    "k_conv_head", "k_conv3x3_h<64, 64, 1>", "k_conv3x3_h<64, 128, 0>", "k_conv3x3_h<128, 128, 1>",
-    "k_conv3x3_h<128, 256, 0>", "k_conv3x3_h<256, 256, 0>", "k_gemm_conv_h<256, 128, 2>", "k_conv3x3_h<256, 128, 0>",
-    "k_conv3x3_h<128, 128, 0>", "k_gemm_conv_h<128, 64, 2>", "k_conv3x3_h<128, 64, 0>", "k_conv_tail_h",
+    "k_conv_head_h16", "k_conv3x3_h16<64, 64, 1>", "k_conv3x3_h16<64, 128, 0>", "k_conv3x3_h16<128, 128, 1>",
+    "k_conv3x3_h16<128, 256, 0>", "k_conv3x3_h16<256, 256, 0>", "k_convt_h<256, 128>", "k_conv3x3_h16<256, 128, 0>",
+    "k_conv3x3_h16<128, 128, 0>", "k_convt_h<128, 64>", "k_conv3x3_h16<128, 64, 0>", "k_conv_tail_h",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -63,7 +63,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], h16_off[NL], head16_off, raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -74,10 +74,11 @@ struct BlobLayout {
             u_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 16, 64);
         }
-        for (int l = 0; l < NL; ++l) {   // fp16-storage path: half weights of the GEMM layers (2 per float slot)
+        for (int l = 0; l < NL; ++l) {   // fp16-storage path: half weights (2 per float slot), in each kernel's fragment order
             h_off[l] = o;
             if (kLayers[l].kind == CONV || kLayers[l].kind == CONVT) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
             if (kLayers[l].kind == TAIL) o = align_up(o + 4 * 64 * 8 / 2, 64);   // k_conv_tail_h: [4 k-steps][64 lanes][8] halfs
+            if (kLayers[l].kind == HEAD) o = align_up(o + 4 * 64 * 8 / 2, 64);   // k_conv_head_h16: [4 channel groups][64 lanes][8] halfs
         }
         for (int l = 0; l < NL; ++l) {
             raw_w_off[l] = o; o = align_up(o + ref_weight_count(kLayers[l]), 64);
@@ -85,11 +86,6 @@ struct BlobLayout {
         }
         tab_off[0] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
         tab_off[1] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
-        for (int l = 0; l < NL; ++l) {   // fp16-storage path, 3x3 layers again in the fragment order of v_mfma_f32_16x16x32_f16
-            h16_off[l] = o;
-            if (kLayers[l].kind == CONV) o = align_up(o + (ref_weight_count(kLayers[l]) + 1) / 2, 64);
-        }
-        head16_off = o; o = align_up(o + 4 * 64 * 8 / 2, 64);   // k_conv_head_h16: [cg][lane][8] halfs
         total = o;
     }
 };
@@ -151,16 +147,14 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
         }
 }
 
-// fp16-storage path: [nb][chunk][tap][k-step][ns][lane = 32*h + j][8] halfs with ci = 32*chunk + 16*kstep + 8*h + e,
-// n' = 64*nb + 32*ns + j — lane (h, j) of v_mfma_f32_32x32x16_f16 holds B[k = 8h..8h+7][col = j].
+// k_convt_h: [nb][chunk][k-step][ns][lane = 32*h + j][8] halfs with ci = 32*chunk + 16*kstep + 8*h + e and column
+// n' = (kh*2 + kw)*COUT + co = 64*nb + 32*ns + j — lane (h, j) of v_mfma_f32_32x32x16_f16 holds B[k = 8h..8h+7][col = j].
 size_t packed_index_h(const LayerDef& L, int co, int ci, int kh, int kw) {
-    const int taps = L.kind == CONV ? 9 : 1;
-    const int tap = L.kind == CONV ? kh * 3 + kw : 0;
-    const int np = L.kind == CONV ? co : (kh * 2 + kw) * L.cout + co;
+    const int np = (kh * 2 + kw) * L.cout + co;
     const int nb = np >> 6, ns = (np >> 5) & 1, j = np & 31;
     const int ck = ci >> 5, ks = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
     const int nchunk = L.cin / 32;
-    return (((((size_t)(nb * nchunk + ck) * taps + tap) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
+    return ((((size_t)(nb * nchunk + ck) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
 }
 
 // k_conv3x3_h16: [nb][32-ch chunk][dx][dy][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
@@ -370,9 +364,9 @@ hipError_t launch_layer(cid_handle_t h, hipStream_t s, const float* blob, int la
 
 hipError_t launch_head(hipStream_t s, const HeadArgs& a, int grid, bool u8, bool f16) {
     if (u8 && f16) hipLaunchKernelGGL((k_conv_head_h16<true>), dim3(grid), dim3(THREADS), 0, s, a);
-    else if (u8) hipLaunchKernelGGL((k_conv_head<true, false>), dim3(grid), dim3(THREADS), 0, s, a);
+    else if (u8) hipLaunchKernelGGL((k_conv_head<true>), dim3(grid), dim3(THREADS), 0, s, a);
     else if (f16) hipLaunchKernelGGL((k_conv_head_h16<false>), dim3(grid), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_head<false, false>), dim3(grid), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_head<false>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int grid, bool u8, bool f16) {
@@ -402,12 +396,8 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
-    if constexpr (MODE == 2) hipLaunchKernelGGL((k_gemm_conv_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    else if (getenv("CID_F16_32X32")) hipLaunchKernelGGL((k_conv3x3_h<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    else {
-        a.w = reinterpret_cast<const _Float16*>(blob + kBlob.h16_off[layer]);
-        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    }
+    if constexpr (MODE == 2) hipLaunchKernelGGL((k_convt_h<CIN, COUT>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -446,7 +436,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
 
     {   // down1[0]: Conv 3->64 + ReLU, NCHW in -> NHWC t0            app.py:43-44
         HeadArgs a;
-        a.in = in; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.head16_off : kBlob.w_off[0]); a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
+        a.in = in; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[0] : kBlob.w_off[0]); a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
         a.N = N; a.H = H; a.W = W;
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
@@ -564,20 +554,18 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         }
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
-            for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                hd[L.kind == CONV ? packed_index_h16(L, co, ci, kh, kw) : packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
+            });
         }
-        if (l == 0) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = co % 16, kg) of group co / 16 holds k = 8kg..8kg+7
-            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.head16_off);
+        if (L.kind == HEAD) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = co % 16, kg) of group co / 16 holds k = 8kg..8kg+7
+            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for (int co = 0; co < 64; ++co)
                 for (int k = 0; k < 32; ++k) {
                     const int tap = k / 3, c = k % 3;
                     const float v = k < 27 ? data[ref_index(L, co, c, tap / 3, tap % 3)] : 0.f;
                     hd[((co >> 4) * 64 + (k >> 3) * 16 + (co & 15)) * 8 + (k & 7)] = (_Float16)v;
                 }
-        }
-        if (L.kind == CONV) {
-            _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h16_off[l]);
-            for_each_weight(L, [&](int co, int ci, int kh, int kw) { hd[packed_index_h16(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)]; });
         }
     }
     h->have[l][is_bias] = true;

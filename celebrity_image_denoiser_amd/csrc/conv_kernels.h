@@ -474,9 +474,9 @@ inline void head_step_of(int k, int& s, int& h) {
 
 struct HeadArgs {
     const void* in;     // fp32 NCHW [N,3,H,W], or (IN_U8) uint8 NHWC [N,H,W,3]
-    const float* w;     // packed [2 ns][14 steps][64 lanes]
+    const float* w;     // packed [2 ns][14 steps][64 lanes] fp32 (k_conv_head) or [4 cg][64 lanes][8] halfs (k_conv_head_h16)
     const float* bias;  // [64]
-    void* out;          // NHWC [N,H,W,64]: fp32, or (OUT_F16) half for the fp16-storage path
+    void* out;          // NHWC [N,H,W,64]: fp32 (k_conv_head) or half (k_conv_head_h16)
     int N, H, W;
     int tiles_x, tiles_y, tiles_total;
     int tiles_per_wg, groups_total, groups_per_xcd;   // a workgroup walks tiles_per_wg consecutive tiles (host: tile_groups)
@@ -498,7 +498,7 @@ inline void tile_groups(Args& a) {
 // A workgroup walks `a.tiles_per_wg` consecutive tiles.  The input elements of the NEXT tile are requested (into
 // registers) before the current tile's MFMAs and stores, so after the first tile no input latency is exposed
 // (tools/headtail_bench: removing the input loads altogether was worth 0.05 of this kernel's 0.23 ms).
-template <bool IN_U8, bool OUT_F16 = false, int ABLATE = 0>
+template <bool IN_U8, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
 #ifndef CID_EXPERIMENTS
     static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
@@ -609,21 +609,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
                 auto val = [&](int ns, int k) { return fmaxf(acc[ns][8 * q + k] + bias_v[ns], 0.f); };
                 auto pix = [&](int k) { return (k & 3) + 8 * (k >> 2) + 4 * h; };
                 const int xq = x0 + 16 * q;
-                if (OUT_F16) {
-                    _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-                    if (full)
-                        wide_store_h_full<16>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
-                    else
-                        wide_store_h<16>(stg, lane, val, pix,
-                                         [&](int px) -> _Float16* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
-                } else {
-                    float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
-                    if (full)
-                        wide_store_full<16, WS_UNPADDED>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
-                    else
-                        wide_store<16, WS_UNPADDED>(stg, lane, val, pix,
-                                       [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
-                }
+                float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
+                if (full)
+                    wide_store_full<16, WS_UNPADDED>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
+                else
+                    wide_store<16, WS_UNPADDED>(stg, lane, val, pix,
+                                                [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
             }
         }
         n = nn; y0 = ny0; x0 = nx0;

@@ -1,23 +1,17 @@
-// conv_kernels_f16.h — fp16-storage / fp32-accumulate variant of the GEMM-shaped layers (BASELINE configs[4]).
+// conv_kernels_f16.h — fp16-storage / fp32-accumulate variant of the forward (BASELINE configs[4]).
 //
-// Same function, tiling and fused epilogues as k_gemm_conv (conv_kernels.h; reference backend/app.py:43-77),
-// with activations and weights held as IEEE half in HBM/LDS and the contraction on
-// v_mfma_f32_32x32x16_f16 (16 input channels per instruction, fp32 accumulators).  Bias, ReLU, max-pool
-// and the transposed-convolution scatter are applied to the fp32 accumulators; results are rounded to half
-// once, at the store.  This is a separate numerical contract from the fp32 path (stated tolerance in
-// tests/test_gpu_parity.py), selected with cid_set_compute_dtype.
+// Same function and fused epilogues as the fp32 kernels (conv_kernels.h; reference backend/app.py:43-103), with activations and
+// weights held as IEEE half in HBM/LDS and the contractions on the fp16 MFMAs with fp32 accumulators.  Bias, ReLU, max-pool and the
+// transposed-convolution scatter are applied to the fp32 accumulators; results are rounded to half once, at the store.  This is a
+// separate numerical contract from the fp32 path (stated tolerance in tests/test_gpu_parity.py), selected with cid_set_compute_dtype.
 //
-//   * workgroup = 8x32 output pixels x 64 channels, wave = 64 pixels x 64 channels (2x2 MFMA tiles);
-//   * K = (32-channel chunk) x (tap) x (16-channel k-step); per k-step and wave: two ds_read_b128 (A: lane
-//     (i,h) takes channels 8h..8h+7 of pixel i) and two 1 KiB B quads (pre-packed per lane), four MFMAs;
-//   * 3x3 layers: the B quads of a chunk (36 KiB, identical for the four waves) come through LDS — fetched once per
-//     workgroup, global -> registers one 16-byte piece per thread and k-step under the previous chunk's MFMAs, written
-//     to LDS at the chunk seam beside the halo tile.  Round 1 had every wave fetch its own copy from L2: 128 B/clk
-//     per CU of B traffic against ~56 B/clk of L2 bandwidth, which capped those layers at 0.33-0.43 of the MFMA rate.
-//     The transposed convolutions (one tap: 4 KiB of B per chunk) keep the per-wave fetch;
-//   * LDS halo tile: pixel = 64 B of data + 16 B pad (5 slots): consecutive pixels are conflict-free for
-//     ds_read_b128; fetched global -> registers -> LDS one piece per step under the MFMAs, like k_gemm_conv;
-//   * store tail: fp32 staging in LDS (wide_store layout), converted to half on the way out, 16 B per lane.
+//   k_conv_head_h16   down1[0]                       v_mfma_f32_16x16x32_f16, K = 27 -> one step
+//   k_conv3x3_h16     the eight 3x3 layers           v_mfma_f32_16x16x32_f16, 32-channel chunks, B by LDS-DMA
+//   k_convt_h         up2, up1                       v_mfma_f32_32x32x16_f16
+//   k_conv_tail_h     upconv1[2] + tanh              v_mfma_f32_32x32x16_f16 (z = x . W per halo pixel, then nine shifted sums)
+//
+// The forward of this path runs at the board's power limit: the 16x16x32 shape moves half the accumulator
+// registers per FLOP of 32x32x16 and sustains 1.22x its rate there (tools/mfma_shape_probe), which is why the heavy layers use it.
 #pragma once
 #include "conv_kernels.h"
 
@@ -38,79 +32,27 @@ struct GemmConvArgsH {
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
 
-// Epilogue shared by the fp16 GEMM kernels: bias (+ReLU) (+2x2 max-pool) (+transposed-conv pixel scatter) on the fp32
-// accumulators, one rounding to half, 16-byte stores through the LDS staging of wide_store_h.
-template <int COUT, int MODE, typename Args>
-__device__ __forceinline__ void gemm_h_epilogue(const Args& a, f32x4* lds, f32x16 (&acc)[2][2], const float (&bias_v)[2], int n, int y0, int x0,
-                                                int wave, int lane, int h, int tap2, int cobase) {
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
-    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
-    if (MODE == 2) {
-        const int kh = tap2 >> 1, kw = tap2 & 1;
-        const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = y0 + 2 * wave + m;
-            _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
-            const int step = 2 * a.out_ps;
-            const bool rowok = y < a.Hc;
-            auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
-            if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
-                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
-            else
-                wide_store_h<32>(stg, lane, val, xo,
-                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = y0 + 2 * wave + m;
-            _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws) * a.out_ps + a.out_coff + cobase;
-            const bool rowok = y < a.Hs;
-            auto val = [&](int ns, int k) { return fmaxf(acc[m][ns][k] + bias_v[ns], 0.f); };
-            if (y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws)
-                wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * a.out_ps, a.out_ps);
-            else
-                wide_store_h<32>(stg, lane, val, xo,
-                                 [&](int px) -> _Float16* { return (rowok && x0 + px < a.Ws) ? orow + (size_t)(x0 + px) * a.out_ps : nullptr; });
-        }
-        if (MODE == 1) {
-            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-            const int py = (y0 >> 1) + wave;
-            _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp) * COUT + cobase;
-            const bool rowok = py < Hp;
-            wide_store_h<16>(stg, lane,
-                             [&](int ns, int q) {
-                                 const int r = (q & 1) * 2 + (q >> 1) * 4;
-                                 const float v = fmaxf(fmaxf(acc[0][ns][r], acc[0][ns][r + 1]), fmaxf(acc[1][ns][r], acc[1][ns][r + 1]));
-                                 return fmaxf(v + bias_v[ns], 0.f);
-                             },
-                             [&](int q) { return (q & 1) + 4 * (q >> 1) + 2 * h; },
-                             [&](int px) -> _Float16* { return (rowok && (x0 >> 1) + px < Wp) ? prow + (size_t)((x0 >> 1) + px) * COUT : nullptr; });
-        }
-    }
-}
-
-template <int CIN, int COUT, int MODE>
-__global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH a) {
-    constexpr int TAPS = (MODE == 2) ? 1 : 9;
-    constexpr int HALO = (MODE == 2) ? 0 : 1;
-    constexpr int LW = TILE_W + 2 * HALO, LH = TILE_H + 2 * HALO, LPIX = LW * LH;
+// ---------------------------------------------------------------------------------------------
+// Transposed convolutions of the fp16-storage path: up2 / up1 = ConvTranspose2d(C, C/2, 2, stride=2) (app.py:63,71), each tap a
+// 1x1 GEMM whose 8x32 input pixels scatter to every other pixel of two output rows.  Workgroup = 256 input pixels x 64 of the
+// 4*COUT columns (one tap, 64 channels), wave = 64 pixels x 64 columns as 2x2 tiles of v_mfma_f32_32x32x16_f16:
+//   * K = 32-channel chunks x two 16-channel k-steps; A: pixel = 64 B of data + 16 B pad in LDS (consecutive pixels conflict-free
+//     for ds_read_b128), fetched global -> registers -> LDS one piece per k-step under the MFMAs; B: two 1 KiB quads per k-step
+//     straight from L2 (pre-packed per lane, packed_index_h), one k-step ahead;
+//   * epilogue: bias on the fp32 accumulators (no activation: app.py:87,94), one rounding to half, 16-byte stores through the LDS
+//     staging of wide_store_h into the concat buffer's first half.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(THREADS, 2) k_convt_h(const GemmConvArgsH a) {
+    constexpr int LW = TILE_W, LPIX = TILE_W * TILE_H;
     constexpr int NSLOT = LPIX * 4;                  // 16-byte data slots (8 halfs) per chunk tile
-    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;
+    constexpr int NLOAD = NSLOT / THREADS;           // 4
     constexpr int NCHUNK = CIN / KCHUNK;             // 32-channel chunks
-    constexpr int NOUT = (MODE == 2) ? 4 * COUT : COUT;
-    constexpr int NB = NOUT / NTILE;
-    constexpr int SPC = TAPS * 2;                    // k-steps (16 channels each) per chunk
-    static_assert(CIN % KCHUNK == 0 && NOUT % NTILE == 0, "layer dims");
-    constexpr bool BLDS = MODE != 2;                 // B through LDS (3x3 layers)
-    constexpr int BSLOTS = BLDS ? SPC * 2 * 64 : 0;  // 16-byte B quads of one chunk: [k-step][ns][lane]
-    constexpr int NBL = BSLOTS / THREADS;            // B pieces per thread and chunk (9)
-    static_assert(BSLOTS % THREADS == 0, "B chunk is a whole number of 4 KiB pieces");
-    constexpr int HALO_SLOTS = LPIX * HPS;
-    constexpr int LDS_SLOTS = ((HALO_SLOTS + BSLOTS) * 16 > 4 * WS_FLOATS * 4) ? HALO_SLOTS + BSLOTS : (4 * WS_FLOATS * 4 + 15) / 16;
-    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile (half) | B chunk (half); later the fp32 store staging
+    constexpr int NOUT = 4 * COUT;
+    constexpr int NB = NOUT / NTILE, CB = COUT / NTILE;
+    constexpr int SPC = 2;                           // k-steps (16 channels each) per chunk
+    static_assert(CIN % KCHUNK == 0 && COUT % NTILE == 0 && NSLOT % THREADS == 0, "layer dims");
+    constexpr int LDS_SLOTS = (LPIX * HPS * 16 > 4 * WS_FLOATS * 4) ? LPIX * HPS : (4 * WS_FLOATS * 4 + 15) / 16;
+    __shared__ f32x4 lds[LDS_SLOTS];                 // input tile (half); later the fp32 store staging
 
     int mt, nb;
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
@@ -118,17 +60,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
-
-    constexpr int CB = COUT / NTILE;
-    const int tap2 = (MODE == 2) ? nb / CB : 0;
-    const int cobase = ((MODE == 2) ? (nb - tap2 * CB) : nb) * NTILE;
+    const int tap2 = nb / CB, cobase = (nb - tap2 * CB) * NTILE;
     float bias_v[2];
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
 
-    // ---- this thread's pieces of the halo tile: piece `it` is data slot s = it*256 + tid (pixel s/4, slot s%4) ----
-    // raw buffer loads over this image (see k_gemm_conv): fixed per-piece byte offsets, scalar chunk offset, the range
-    // check supplies the zero padding
+    // this thread's pieces of the input tile: piece `it` is data slot s = it*256 + tid (pixel s/4, slot s%4); raw buffer loads over
+    // this image with fixed per-piece byte offsets and a scalar chunk offset, out-of-image pieces out of range (read as zero)
     const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
     unsigned goff[NLOAD];
@@ -136,17 +74,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
     for (int it = 0; it < NLOAD; ++it) {
         const int s = it * THREADS + tid;
         const int p = s >> 2, c = s & 3;
-        const int hy = p / LW, hx = p - hy * LW;
-        const int gy = y0 - HALO + hy, gx = x0 - HALO + hx;
-        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+        const int gy = y0 + p / LW, gx = x0 + p % LW;
+        const bool ok = (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
         goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 8) * 2) : 0x7ffffff0u;
     }
     const int wslot = (tid >> 2) * HPS + (tid & 3);   // piece `it` lands at wslot + it*64*HPS
-    auto halo_load = [&](int it, int ck) -> f32x4 {
+    auto tile_load = [&](int it, int ck) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * (KCHUNK * 2), 0));
-    };
-    auto halo_store = [&](int it, f32x4 v) {
-        if ((it + 1) * THREADS <= NSLOT || it * THREADS + tid < NSLOT) lds[wslot + it * 64 * HPS] = v;
     };
 
     f32x16 acc[2][2];
@@ -157,63 +91,43 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
 
-    const int pbase0 = ((2 * wave) * LW + i) * HPS + h;   // slot of (row 2*wave, column i), tap (0,0), k-step 0
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * NOUT * TAPS * 2, 0x00020000);
+    const int pbase0 = ((2 * wave) * LW + i) * HPS + h;   // slot of (row 2*wave, column i), k-step 0
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * NOUT * 2, 0x00020000);
     const int wbase = nb * NCHUNK * SPC * 2048, wlane = lane * 16;
     auto b_load = [&](int gstep, int ns) -> f16x8 {   // step g is the 2 KiB at (nb*NCHUNK*SPC + g)*2048 bytes
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, wbase + gstep * 2048 + ns * 1024, 0));
     };
-    // BLDS: piece j of chunk ck = the 4 KiB at byte (chunk base) + 4096 j, 16 bytes per thread; it lands in B slot 256 j + tid
-    auto bpiece_load = [&](int j, int ck) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16, wbase + ck * SPC * 2048 + j * 4096, 0));
-    };
-    f32x4* const ldsb = lds + HALO_SLOTS;
 
     f32x4 pre[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
-    f32x4 bpre[BLDS ? NBL : 1];
+    for (int it = 0; it < NLOAD; ++it) pre[it] = tile_load(it, 0);
     f16x8 bcur[2], bnxt[2];
-    if (BLDS) {
+    bcur[0] = b_load(0, 0);
+    bcur[1] = b_load(0, 1);
 #pragma unroll
-        for (int j = 0; j < NBL; ++j) bpre[j] = bpiece_load(j, 0);
-    } else {
-        bcur[0] = b_load(0, 0);
-        bcur[1] = b_load(0, 1);
-    }
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
-    if (BLDS) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
-    }
+    for (int it = 0; it < NLOAD; ++it) lds[wslot + it * 64 * HPS] = pre[it];
     __syncthreads();
 
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
-    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;   // B quad (k-step st, ns) of this lane at [(2 st + ns) * 64]
-    static_assert(!BLDS || NLOAD + NBL <= SPC, "one prefetch piece per k-step");
     auto chunk = [&](auto pref_tag, int ck) {
         constexpr bool PREF = decltype(pref_tag)::value;
         f16x8 acur[2], anxt[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * HPS];
-        if (BLDS) { bcur[0] = ldsbh[0]; bcur[1] = ldsbh[64]; }
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
             if (st + 1 < SPC) {
-                const int t2 = (st + 1) >> 1, ks2 = (st + 1) & 1;
-                const int off = ((TAPS == 9) ? ((t2 / 3) * LW + (t2 % 3)) : 0) * HPS + 2 * ks2;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + off];
+                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + 2 * (st + 1)];
             }
-            if (BLDS) {
-                if (st + 1 < SPC) { bnxt[0] = ldsbh[(2 * (st + 1)) * 64]; bnxt[1] = ldsbh[(2 * (st + 1) + 1) * 64]; }
-                if (PREF && st >= NLOAD && st - NLOAD < NBL) bpre[st - NLOAD] = bpiece_load(st - NLOAD, ck + 1);
-            } else if (PREF || st + 1 < SPC) {
+            if (PREF || st + 1 < SPC) {
                 bnxt[0] = b_load(ck * SPC + st + 1, 0);
                 bnxt[1] = b_load(ck * SPC + st + 1, 1);
             }
-            if (PREF && st < NLOAD) pre[st] = halo_load(st, ck + 1);
+            if (PREF) {
+#pragma unroll
+                for (int it = st * (NLOAD / SPC); it < (st + 1) * (NLOAD / SPC); ++it) pre[it] = tile_load(it, ck + 1);
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -223,169 +137,37 @@ __global__ void __launch_bounds__(THREADS, 2) k_gemm_conv_h(const GemmConvArgsH 
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
             }
-            if (BLDS ? (st + 1 < SPC) : (PREF || st + 1 < SPC)) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
+            if (PREF || st + 1 < SPC) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
         }
         if (PREF) {
-            if (SPC < NLOAD) {
-#pragma unroll
-                for (int it = SPC; it < NLOAD; ++it) pre[it] = halo_load(it, ck + 1);
-            }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < NLOAD; ++it) halo_store(it, pre[it]);
-            if (BLDS) {
-#pragma unroll
-                for (int j = 0; j < NBL; ++j) ldsb[j * THREADS + tid] = bpre[j];
-            }
+            for (int it = 0; it < NLOAD; ++it) lds[wslot + it * 64 * HPS] = pre[it];
             __syncthreads();
         }
     };
     for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
     chunk(std::false_type{}, NCHUNK - 1);
 
-    gemm_h_epilogue<COUT, MODE>(a, lds, acc, bias_v, n, y0, x0, wave, lane, h, tap2, cobase);
-}
-
-// ---------------------------------------------------------------------------------------------
-// 3x3 layers of the fp16-storage path, second form: 16-channel chunks, three workgroups per CU.
-//
-// With fp16 MFMA a workgroup's main loop is short (CIN = 128: 288 MFMAs = 9k cycles per wave) next to its prologue
-// (first loads: memory latency) and epilogue (conversion, staging, 32 KiB of stores), so what bounds these layers is how many
-// workgroups a CU can interleave.  k_gemm_conv_h holds a 32-channel halo tile plus the chunk's B quads in 64 KiB of LDS:
-// two per CU.  Here a chunk is 16 channels (one MFMA k-step per tap): halo tile 340 pixels x 48 B (32 B data + 16 B pad:
-// three 16-byte slots, conflict-free for ds_read_b128) + 18 KiB of B = 34 KiB, under 168 VGPRs: three per CU.
-// Same tile (8x32 pixels x 64 channels, wave = 2 rows), same packed weights (a 16-channel chunk is k-step `ks` of the
-// 32-channel chunk `ck32`: its quads (tap, ns) lie 4 KiB apart), same epilogue.
-template <int CIN, int COUT, int MODE>
-__global__ void __launch_bounds__(THREADS, MODE == 0 ? 4 : 3) k_conv3x3_h(const GemmConvArgsH a) {
-    static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
-    constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;
-    constexpr int PS3 = 3;                           // LDS slots per pixel: 2 data (16 halfs) + 1 pad
-    constexpr int NSLOT = LPIX * 2;                  // 16-byte data slots per chunk tile
-    constexpr int NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 3
-    constexpr int NCHUNK = CIN / 16, NCH32 = CIN / 32;
-    constexpr int NB = COUT / NTILE;
-    constexpr int SPC = 9;                           // k-steps per chunk = taps
-    constexpr int BSLOTS = SPC * 2 * 64;             // B quads of one chunk: [tap][ns][lane]
-    constexpr int NBL = (BSLOTS + THREADS - 1) / THREADS;    // 5 pieces per thread (the last one half used)
-    constexpr int HALO_SLOTS = LPIX * PS3;
-    constexpr int LDS_SLOTS = ((HALO_SLOTS + BSLOTS) * 16 > 4 * WS_FLOATS * 4) ? HALO_SLOTS + BSLOTS : (4 * WS_FLOATS * 4 + 15) / 16;
-    __shared__ f32x4 lds[LDS_SLOTS];                 // halo tile | B chunk; later the fp32 store staging (34,816 B)
-
-    int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
-    int n, ty, tx;
-    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
-    const int cobase = nb * NTILE;
-    float bias_v[2];
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
-
-    // halo pieces: data slot s = it*256 + tid = (pixel s>>1, half-chunk s&1); out-of-image pieces read as zero (range check)
-    const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
-    unsigned goff[NLOAD];
-    int hslot[NLOAD];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-        const int s = it * THREADS + tid;
-        const int p = s >> 1, c = s & 1;
-        const int hy = p / LW, hx = p - hy * LW;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = (s < NSLOT) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 8) * 2) : 0x7ffffff0u;
-        hslot[it] = s < NSLOT ? p * PS3 + c : -1;
-    }
-    auto halo_load = [&](int it, int ck) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * 32, 0));
-    };
-    // B pieces: slot = j*256 + tid = quad (tap, ns) = slot >> 6, lane = slot & 63; in the packed weights quad (tap, ns) of the
-    // 16-channel chunk (ck32, ks) is the 1 KiB at ((ck32*9 + tap)*4 + ks*2 + ns) * 1024 past the column block's base
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
-    const int wbase = nb * NCH32 * 36 * 1024;
-    unsigned boff[NBL];
-#pragma unroll
-    for (int j = 0; j < NBL; ++j) {
-        const int slot = j * THREADS + tid, quad = slot >> 6;
-        boff[j] = slot < BSLOTS ? (unsigned)(((quad >> 1) * 4 + (quad & 1)) * 1024 + (slot & 63) * 16) : 0x7ffffff0u;
-    }
-    auto b_load = [&](int j, int ck) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, boff[j], wbase + ((ck >> 1) * 36 + (ck & 1) * 2) * 1024, 0));
-    };
-    f32x4* const ldsb = lds + HALO_SLOTS;
-    auto stage_to_lds = [&](const f32x4 (&pre)[NLOAD], const f32x4 (&bpre)[NBL]) {
-#pragma unroll
-        for (int it = 0; it < NLOAD; ++it)
-            if (hslot[it] >= 0) lds[hslot[it]] = pre[it];
-#pragma unroll
-        for (int j = 0; j < NBL; ++j)
-            if ((j + 1) * THREADS <= BSLOTS || j * THREADS + tid < BSLOTS) ldsb[j * THREADS + tid] = bpre[j];
-    };
-
-    f32x4 pre[NLOAD], bpre[NBL];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, 0);
-#pragma unroll
-    for (int j = 0; j < NBL; ++j) bpre[j] = b_load(j, 0);
-    f32x16 acc[2][2];
-    stage_to_lds(pre, bpre);
+    // ---- epilogue: tap (kh, kw) of input pixel (y, x) is output pixel (2y + kh, 2x + kw) ----
     __syncthreads();
-
-    const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
-    const f16x8* ldsbh = reinterpret_cast<const f16x8*>(ldsb) + lane;   // B quad (tap, ns) of this lane at [(2 tap + ns) * 64]
-    const int pbase0 = ((2 * wave) * LW + i) * PS3 + h;                 // slot of (row 2*wave, column i), tap (0,0)
-    auto chunk = [&](auto first_tag, auto pref_tag, int ck) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr bool PREF = decltype(pref_tag)::value;
-        f16x8 acur[2], anxt[2], bcur[2], bnxt[2];
+    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
+    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
+    const int kh = tap2 >> 1, kw = tap2 & 1;
+    const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * PS3];
-        bcur[0] = ldsbh[0]; bcur[1] = ldsbh[64];
-        if (PREF) {   // the whole next chunk is requested before this chunk's first MFMA: at fp16 rates a chunk is only ~1-3k cycles of
-                      // matrix work, and a request issued in its middle would still be in flight at the seam
-#pragma unroll
-            for (int it = 0; it < NLOAD; ++it) pre[it] = halo_load(it, ck + 1);
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) bpre[j] = b_load(j, ck + 1);
-        }
-#pragma unroll
-        for (int st = 0; st < SPC; ++st) {
-            if (st + 1 < SPC) {
-                const int off = (((st + 1) / 3) * LW + ((st + 1) % 3)) * PS3;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * PS3 + off];
-                bnxt[0] = ldsbh[(2 * (st + 1)) * 64]; bnxt[1] = ldsbh[(2 * (st + 1) + 1) * 64];
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) {
-                    if (FIRST && st == 0) {
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], zero, 0, 0, 0);
-                    } else {
-                        acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], acc[m][ns], 0, 0, 0);
-                    }
-                }
-            if (st + 1 < SPC) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
-                bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
-            }
-        }
-        if (PREF) {
-            __syncthreads();          // every wave is done reading this chunk's tile and B
-            stage_to_lds(pre, bpre);
-            __syncthreads();
-        }
-    };
-    static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
-    chunk(std::true_type{}, std::true_type{}, 0);
-    for (int ck = 1; ck + 1 < NCHUNK; ++ck) chunk(std::false_type{}, std::true_type{}, ck);
-    chunk(std::false_type{}, std::false_type{}, NCHUNK - 1);
-    gemm_h_epilogue<COUT, MODE>(a, lds, acc, bias_v, n, y0, x0, wave, lane, h, 0, cobase);
+    for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
+        const int step = 2 * a.out_ps;
+        const bool rowok = y < a.Hc;
+        auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
+        if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
+            wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
+        else
+            wide_store_h<32>(stg, lane, val, xo,
+                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+    }
 }
 
 // Row permutation of the 16x16x32 kernels: MFMA row i of a 16-pixel group is pixel h16_prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1).

@@ -20,7 +20,7 @@ static Variant head(const char* name, int N, int H, int W, float* in, float* w, 
     if (tpw > 0) { a.tiles_per_wg = tpw; a.groups_total = (a.tiles_total + tpw - 1) / tpw; a.groups_per_xcd = (a.groups_total + 7) / 8; }
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
     const int grid = 8 * a.groups_per_xcd;
-    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_head<false, false, ABLATE>), dim3(grid), dim3(THREADS), extra_lds, s, a); }};
+    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_head<false, ABLATE>), dim3(grid), dim3(THREADS), extra_lds, s, a); }};
 }
 template <int ABLATE>
 static Variant tail(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int extra_lds, int tpw = 0) {
