@@ -1,0 +1,32 @@
+"""Debug aid (GPU): per-stage max error of conv_algo="winograd43" against the tiny golden fixtures, and run-to-run determinism."""
+import os, sys, glob, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+import celebrity_image_denoiser_amd as cid
+from celebrity_image_denoiser_amd import synth
+gd = os.path.join(os.path.dirname(__file__), "..", "..", "..", "tests", "golden")
+STAGES = ["down1", "down2", "bottleneck", "up2", "upconv2", "up1"]
+for algo in sys.argv[1:] or ["winograd43"]:
+    for wset in ("default",):
+        m = cid.load(synth.make_state_dict(wset), device="cuda:0", strict=True)
+        m.conv_algo = algo
+        m.tail_algo = "fused"
+        for name in ("tiny_%s_16x16" % wset, "tiny_%s_20x24" % wset):
+            g = np.load(os.path.join(gd, name + ".npz"))
+            x = torch.from_numpy(g["x"]).to("cuda:0")
+            y1 = m(x).cpu().numpy(); y2 = m(x).cpu().numpy()
+            n, _, h, w = g["x"].shape
+            print(algo, name, "out err %.3e   rerun diff %.3e" % (np.abs(y1 - g["out"]).max(), np.abs(y1 - y2).max()))
+            for st in STAGES:
+                try:
+                    got = m.stage_output(st, n, h, w).cpu().numpy()
+                except KeyError:
+                    continue
+                ref = g[st][:, :, :got.shape[2], :got.shape[3]]
+                d = np.abs(got - ref)
+                idx = np.unravel_index(d.argmax(), d.shape)
+                print("   %-11s |ref| %.3f  max err %.3e at %s   frac>1e-5: %.4f" % (st, np.abs(ref).max(), d.max(), idx, (d > 1e-5).mean()))
+        x = torch.from_numpy(synth.make_batch(2, 128, 128, 5)[0]).to("cuda:0")
+        ya = m(x).cpu().numpy(); yb = m(x).cpu().numpy()
+        m.conv_algo = "winograd64"
+        yr = m(x).cpu().numpy()
+        print(algo, "128x128: vs winograd64 %.3e  rerun diff %.3e" % (np.abs(ya - yr).max(), np.abs(ya - yb).max()))
