@@ -114,7 +114,10 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     // ---- LDS-DMA sources (same table format as k_wino64_conv) ----
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
-    unsigned voff[RW];
+    // per-lane byte offsets of this wave's DMA rounds, parked in the LDS beyond the two buffers (five registers the main loop
+    // cannot spare; one ds_read_b32 per round instead)
+    unsigned* const voff_tab = reinterpret_cast<unsigned*>(lds + 2 * BUF) + wave * (RW * 64) + lane;
+    static_assert(2 * BUF * 16 + 6 * RW * 64 * 4 <= LDS_SLOTS_K * 16, "offset table fits behind the buffers");
     {
         unsigned ent[RW];
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
             const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
             const unsigned off = (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4);
             const unsigned keep = ok ? 0xffffffffu : 0u;
-            voff[m] = (off & keep) | (0x7ffffff0u & ~keep);
+            voff_tab[m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
         }
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
@@ -134,7 +137,8 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
         if (wave + 6 * m < NROUND) {                   // wave-uniform
             const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 6 * m) * 64) * 16);
             const int soff = ck * (WK * 4);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
+            const unsigned vo = voff_tab[m * 64];
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vo), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
         }
     };
     auto dma_chunk = [&](int buf, int ck) {
@@ -169,40 +173,41 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     __syncthreads();
 
     f32x4 acc[6][4];   // [position b][channel group cg]; first written by the zero-C MFMAs of unit 0
-    float vcur[6][2], vnxt[6][2];
+    float vcur[6][2];
     f32x2 raw[4];
-    float t[6][2];
+    // the next unit's V, column by column: V0 = P0, V1/V2 = E12 +- O12, V3/V4 = E34 +- O34, V5 = P5 (the +-p rows of B^T share
+    // their even and odd parts); a column's t = sum_r B^T[a][r] d[r] is folded into these six as soon as it is formed
+    float P0[2], E12[2], O12[2], E34[2], O34[2], P5[2];
     auto read_col = [&](int bufhalf, int c) {              // bufhalf = 2 * buf * BUF + s2 (f32x2 units)
 #pragma unroll
         for (int j = 0; j < 4; ++j) raw[j] = lds2[bufhalf + rbase[j] + col_off(c)];
     };
-    auto make_t = [&](int c) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            t[c][e] = __builtin_fmaf(cf[3], raw[3][e], __builtin_fmaf(cf[2], raw[2][e], __builtin_fmaf(cf[1], raw[1][e], cf[0] * raw[0][e])));
-    };
-    auto make_v = [&](float (&v)[6][2], int part) {       // part 0: b = 0, 1, 2; part 1: b = 3, 4, 5
+    auto fold_col = [&](int c) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (part == 0) {
-                v[0][e] = __builtin_fmaf(1.265625f, t[0][e], __builtin_fmaf(-2.8125f, t[2][e], t[4][e]));
-                const float ev = __builtin_fmaf(-2.25f, t[2][e], t[4][e]);
-                const float od = __builtin_fmaf(-1.6875f, t[1][e], 0.75f * t[3][e]);
-                v[1][e] = ev + od;
-                v[2][e] = ev - od;
-            } else {
-                const float ev = __builtin_fmaf(-0.5625f, t[2][e], t[4][e]);
-                const float od = __builtin_fmaf(-0.84375f, t[1][e], 1.5f * t[3][e]);
-                v[3][e] = ev + od;
-                v[4][e] = ev - od;
-                v[5][e] = __builtin_fmaf(1.265625f, t[1][e], __builtin_fmaf(-2.8125f, t[3][e], t[5][e]));
-            }
+            const float t = __builtin_fmaf(cf[3], raw[3][e], __builtin_fmaf(cf[2], raw[2][e], __builtin_fmaf(cf[1], raw[1][e], cf[0] * raw[0][e])));
+            if (c == 0) P0[e] = 1.265625f * t;
+            if (c == 1) { O12[e] = -1.6875f * t; O34[e] = -0.84375f * t; P5[e] = 1.265625f * t; }
+            if (c == 2) { P0[e] = __builtin_fmaf(-2.8125f, t, P0[e]); E12[e] = -2.25f * t; E34[e] = -0.5625f * t; }
+            if (c == 3) { O12[e] = __builtin_fmaf(0.75f, t, O12[e]); O34[e] = __builtin_fmaf(1.5f, t, O34[e]); P5[e] = __builtin_fmaf(-2.8125f, t, P5[e]); }
+            if (c == 4) { P0[e] += t; E12[e] += t; E34[e] += t; }
+            if (c == 5) P5[e] += t;
+        }
+    };
+    auto finish_v = [&]() {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            vcur[0][e] = P0[e];
+            vcur[1][e] = E12[e] + O12[e];
+            vcur[2][e] = E12[e] - O12[e];
+            vcur[3][e] = E34[e] + O34[e];
+            vcur[4][e] = E34[e] - O34[e];
+            vcur[5][e] = P5[e];
         }
     };
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { read_col(0, c); make_t(c); }
-    make_v(vcur, 0);
-    make_v(vcur, 1);
+    for (int c = 0; c < 6; ++c) { read_col(0, c); fold_col(c); }
+    finish_v();
 
     // Chunk ck in LDS buffer PAR: two units (s2 = 0, 1: the two channel pairs of every quad).  Unit = 12 groups of four MFMAs
     // (k-step e2 outer, position b inner, the four channel groups innermost); under them the next unit's V is built.
@@ -221,12 +226,10 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
             for (int grp = 0; grp < 12; ++grp) {
                 const int e2 = grp / 6, b = grp - 6 * e2;
                 if (build) {   // column grp is read here and folded one group later, under four MFMAs
-                    if (grp >= 1 && grp <= 6) make_t(grp - 1);
+                    if (grp >= 1 && grp <= 6) fold_col(grp - 1);
                     if (grp < 6) read_col(nhalf, grp);
-                    if (grp == 8) make_v(vnxt, 0);
-                    if (grp == 10) make_v(vnxt, 1);
                 }
-                if (DMA && k == 1 && grp < RW) dma_round(PAR, ck + 2, grp);
+                if (DMA && k == 1 && grp >= 6 && grp - 6 < RW) dma_round(PAR, ck + 2, grp - 6);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
                     if (FIRST && k == 0 && e2 == 0) {
@@ -241,10 +244,7 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
                 else if (MORE || k == 0) bq[b] = b_load(gu + 1, grp - 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (build) {
-#pragma unroll
-                for (int b = 0; b < 6; ++b) { vcur[b][0] = vnxt[b][0]; vcur[b][1] = vnxt[b][1]; }
-            }
+            if (build) finish_v();
             if (MORE && k == 0) {
                 // every DMA of this wave for chunk ck+1 is older than the last six B refills
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");

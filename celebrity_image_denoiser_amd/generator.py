@@ -203,8 +203,8 @@ class DenoiseGenerator(nn.Module):
     # (include/cid.h; 2048x2048 is the first square that does not fit).  The reference takes any size (app.py:80-103 is fully
     # convolutional), so larger images are cut into horizontal stripes here: output rows [a, b) (multiples of 8) are computed
     # from input rows [a - 32, b + 32).  A network output depends on input rows within +-20 (2 + 4 + 8 + 4 + 2 rows through
-    # the three resolutions, plus pool alignment), stripe origins are multiples of 8 (pool windows, transposed-conv phases
-    # and the 2x2 Winograd tiles keep their alignment down to the quarter-resolution layers: a pixel that changed its place
+    # the three resolutions, plus pool alignment), stripe origins are multiples of 16 (pool windows, transposed-conv phases
+    # and the 4x4 Winograd tiles keep their alignment down to the quarter-resolution layers: a pixel that changed its place
     # inside a Winograd tile would be summed in another order), and every pixel is computed by the same instructions, so
     # the assembled result equals the single-call result bit for bit (tests: forced small stripes on a mid-size image).
     STRIPE_HALO = 32
@@ -222,9 +222,9 @@ class DenoiseGenerator(nn.Module):
         ho, wo = 4 * (h // 4), 4 * (w // 4)
         halo = self.STRIPE_HALO
         if stripe_rows is None:
-            stripe_rows = (self.MAX_PIXELS_PER_CALL // w - 2 * halo) // 8 * 8
-        if stripe_rows < 8 or stripe_rows % 8:
-            raise RuntimeError(f"image rows of {w} pixels are too wide to cut into stripes of at least 8 rows")
+            stripe_rows = (self.MAX_PIXELS_PER_CALL // w - 2 * halo) // 16 * 16
+        if stripe_rows < 16 or stripe_rows % 16:
+            raise RuntimeError(f"image rows of {w} pixels are too wide to cut into stripes of at least 16 rows")
         shape = (n, ho, wo, 3) if out_u8 else (n, 3, ho, wo)
         y = self._output(out, shape, torch.uint8 if out_u8 else torch.float32, x.device)
         for a in range(0, ho, stripe_rows):

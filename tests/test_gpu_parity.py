@@ -647,16 +647,16 @@ def test_striped_forward_equals_single_call_bit_for_bit(models):
     """Images beyond one call's size limit (cid_forward refuses H*W >= 4,194,303: 32-bit per-image addressing) are cut into
     horizontal stripes with a 32-row halo (generator._forward_striped).  Property: with stripes FORCED on a mid-size image
     the assembled result is the single-call result, bit for bit — fp32 and uint8 formats, a height that is not a multiple
-    of 4 (crop path at the bottom), stripes of 8, 16 and 56 rows (multiples of 8: Winograd tile alignment at quarter resolution)."""
+    of 4 (crop path at the bottom), stripes of 16, 32 and 64 rows (multiples of 16: the 4x4 Winograd tiles keep their alignment at quarter resolution)."""
     m = models["hot"]
     x, _, noisy = synth.make_batch(2, 150, 70, first_index=6000)
     xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
     want, want8 = m(xd).clone(), m.forward_u8(ud).clone()
-    for rows in (8, 16, 56):
+    for rows in (16, 32, 64):
         assert torch.equal(m._forward_striped(xd, out_u8=False, stripe_rows=rows), want), (rows, float((m._forward_striped(xd, out_u8=False, stripe_rows=rows) - want).abs().max()))
         assert torch.equal(m._forward_striped(ud, out_u8=True, stripe_rows=rows), want8), rows
     with pytest.raises(RuntimeError):
-        m._forward_striped(xd, out_u8=False, stripe_rows=12)
+        m._forward_striped(xd, out_u8=False, stripe_rows=24)
 
 
 def test_image_beyond_the_single_call_limit(models, weight_sets):
