@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--weights", default="default", choices=["default", "hot"])
-    ap.add_argument("--algo", default="winograd64", choices=["winograd64", "winograd43", "direct"],
+    ap.add_argument("--algo", default="winograd64", choices=["winograd64", "winograd42", "direct"],
                     help="algorithm of the eight 3x3 GEMM layers (all fp32): winograd64 = Winograd F(2x2,3x3), 64 output channels per "
                          "workgroup (default); direct = 9-tap implicit GEMM")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],

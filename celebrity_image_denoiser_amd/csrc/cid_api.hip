@@ -5,7 +5,7 @@
 #include "../../include/cid.h"
 #include "conv_kernels.h"
 #include "wino64_kernels.h"
-#include "wino43_kernels.h"
+#include "wino42_kernels.h"
 #include "conv_kernels_f16.h"
 
 #include <dlfcn.h>
@@ -64,7 +64,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u43_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab43_off[3], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[3], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -87,13 +87,13 @@ struct BlobLayout {
         }
         tab_off[0] = o; o = align_up(o + wino_slot_table(32, 1, nullptr), 64);   // Winograd LDS slot tables, TC = 32 and 16
         tab_off[1] = o; o = align_up(o + wino_slot_table(16, 2, nullptr), 64);
-        for (int l = 0; l < NL; ++l) {   // Winograd F(4x4,3x3): U at 36 positions
-            u43_off[l] = o;
-            if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 36, 64);
+        for (int l = 0; l < NL; ++l) {   // Winograd F(4x2,3x3): U at 24 positions
+            u42_off[l] = o;
+            if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 24, 64);
         }
-        tab43_off[0] = o; o = align_up(o + wino43_slot_table<16>(nullptr), 64);   // its LDS slot tables, TC = 16, 8, 4
-        tab43_off[1] = o; o = align_up(o + wino43_slot_table<8>(nullptr), 64);
-        tab43_off[2] = o; o = align_up(o + wino43_slot_table<4>(nullptr), 64);
+        tab42_off[0] = o; o = align_up(o + wino42_slot_table<16>(nullptr), 64);   // its LDS slot tables, TC = 16, 8, 4
+        tab42_off[1] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);
+        tab42_off[2] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
         total = o;
     }
 };
@@ -155,31 +155,32 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
         }
 }
 
-// Winograd F(4x4,3x3) filter transform U = G g G^T at the points 0, 3/4, -3/4, 3/2, -3/2, inf (36 values per (co, ci)), in
-// double, rounded once to fp32, laid out for k_wino43_conv:
+// Winograd F(4x2,3x3) filter transform U = G2 g G4^T — rows by the F(2,3) matrix of pack_winograd_u, columns by F(4,3) at the
+// points 0, 3/4, -3/4, 3/2, -3/2, inf (24 values per (co, ci)) —, in double, rounded once to fp32, laid out for k_wino42_conv:
 //   [nb = co/64][unit = ci/8][a][q = 6*e2 + b][lane = 16*g + j][cg],   ci = 16*(unit/2) + 4*g + 2*(unit%2) + e2,  co = 64*nb + 16*cg + j
 // (one 16-byte quad per lane = the four channel groups of position (a, b) at k-step e2: one V value, four MFMAs)
-void pack_winograd43_u(const LayerDef& L, const float* w, float* dst) {
-    static const double G[6][3] = {{64.0 / 81, 0, 0},
-                                   {-128.0 / 243, -32.0 / 81, -8.0 / 27},
-                                   {-128.0 / 243, 32.0 / 81, -8.0 / 27},
-                                   {32.0 / 243, 16.0 / 81, 8.0 / 27},
-                                   {32.0 / 243, -16.0 / 81, 8.0 / 27},
-                                   {0, 0, 1}};
+void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
+    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const double G4[6][3] = {{64.0 / 81, 0, 0},
+                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27},
+                                    {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},
+                                    {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                    {0, 0, 1}};
     const int nunit = L.cin / 8;
     for (int co = 0; co < L.cout; ++co)
         for (int ci = 0; ci < L.cin; ++ci) {
             const float* g = w + ((size_t)co * L.cin + ci) * 9;
-            double tmp[6][3];
-            for (int a = 0; a < 6; ++a)
-                for (int q = 0; q < 3; ++q) tmp[a][q] = G[a][0] * g[0 * 3 + q] + G[a][1] * g[1 * 3 + q] + G[a][2] * g[2 * 3 + q];
+            double tmp[4][3];
+            for (int a = 0; a < 4; ++a)
+                for (int q = 0; q < 3; ++q) tmp[a][q] = G2[a][0] * g[0 * 3 + q] + G2[a][1] * g[1 * 3 + q] + G2[a][2] * g[2 * 3 + q];
             const int nb = co >> 6, cg = (co >> 4) & 3, j = co & 15;
             const int ck = ci >> 4, gg = (ci >> 2) & 3, s2 = (ci >> 1) & 1, e2 = ci & 1;
             const int unit = ck * 2 + s2;
-            for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 6; ++b) {
-                    const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
-                    dst[((((((size_t)nb * nunit + unit) * 6 + a) * 12 + (6 * e2 + b)) * 64) + gg * 16 + j) * 4 + cg] = (float)u;
+                    const double u = tmp[a][0] * G4[b][0] + tmp[a][1] * G4[b][1] + tmp[a][2] * G4[b][2];
+                    dst[((((((size_t)nb * nunit + unit) * 4 + a) * 12 + (6 * e2 + b)) * 64) + gg * 16 + j) * 4 + cg] = (float)u;
                 }
         }
 }
@@ -262,9 +263,9 @@ struct cid_handle_s {
         std::memset(have, 0, sizeof(have));
         wino_slot_table(32, 1, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
         wino_slot_table(16, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
-        wino43_slot_table<16>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab43_off[0]));
-        wino43_slot_table<8>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab43_off[1]));
-        wino43_slot_table<4>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab43_off[2]));
+        wino42_slot_table<16>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[0]));
+        wino42_slot_table<8>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[1]));
+        wino42_slot_table<4>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[2]));
     }
 };
 
@@ -369,14 +370,14 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
 }
 
 template <int CIN, int COUT, bool POOL, int TC>
-hipError_t launch_wino43_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
+hipError_t launch_wino42_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
     WinoArgs a = base;
     constexpr int TRW = 16 / TC;
-    a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab43_off[tab]);
-    a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 4 * TRW);
+    a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab42_off[tab]);
+    a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino43_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN2)), dim3(W43_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN2)), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -392,11 +393,11 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
-    if (algo == CID_ALGO_WINOGRAD43) {   // 16 tiles of 4x4 per workgroup: 16 x 1, 8 x 2 or 4 x 4 by the width of the rows
-        a.u = blob + kBlob.u43_off[layer];
-        if (Wc > 32) return launch_wino43_tc<CIN, COUT, MODE == 1, 16>(s, a, blob, 0);
-        if (Wc > 16) return launch_wino43_tc<CIN, COUT, MODE == 1, 8>(s, a, blob, 1);
-        return launch_wino43_tc<CIN, COUT, MODE == 1, 4>(s, a, blob, 2);
+    if (algo == CID_ALGO_WINOGRAD42) {   // 16 tiles of 4x2 pixels per workgroup: 16 x 1, 8 x 2 or 4 x 4 by the width of the rows
+        a.u = blob + kBlob.u42_off[layer];
+        if (Wc > 32) return launch_wino42_tc<CIN, COUT, MODE == 1, 16>(s, a, blob, 0);
+        if (Wc > 16) return launch_wino42_tc<CIN, COUT, MODE == 1, 8>(s, a, blob, 1);
+        return launch_wino42_tc<CIN, COUT, MODE == 1, 4>(s, a, blob, 2);
     }
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
@@ -603,7 +604,7 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         for_each_weight(L, [&](int co, int ci, int kh, int kw) { dst[packed_index(L, co, ci, kh, kw)] = data[ref_index(L, co, ci, kh, kw)]; });
         std::memcpy(h->staging.data() + kBlob.raw_w_off[l], data, sizeof(float) * ref_weight_count(L));
         if (L.kind == CONV) pack_winograd_u(L, data, h->staging.data() + kBlob.u_off[l]);
-        if (L.kind == CONV) pack_winograd43_u(L, data, h->staging.data() + kBlob.u43_off[l]);
+        if (L.kind == CONV) pack_winograd42_u(L, data, h->staging.data() + kBlob.u42_off[l]);
         if (L.kind == TAIL) {   // half copy for k_conv_tail_h: [k-step s][lane = 32*h + col][e], ci = 16*s + 8*h + e, col = 3*tap + co
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
@@ -786,7 +787,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
 
 int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
-    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64 && algo != CID_ALGO_WINOGRAD43) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
+    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64 && algo != CID_ALGO_WINOGRAD42) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
     return CID_OK;
 }

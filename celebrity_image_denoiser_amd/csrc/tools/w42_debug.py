@@ -1,11 +1,11 @@
-"""Debug aid (GPU): per-stage max error of conv_algo="winograd43" against the tiny golden fixtures, and run-to-run determinism."""
+"""Debug aid (GPU): per-stage max error of conv_algo="winograd42" against the tiny golden fixtures, and run-to-run determinism."""
 import os, sys, glob, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 import celebrity_image_denoiser_amd as cid
 from celebrity_image_denoiser_amd import synth
 gd = os.path.join(os.path.dirname(__file__), "..", "..", "..", "tests", "golden")
 STAGES = ["down1", "down2", "bottleneck", "up2", "upconv2", "up1"]
-for algo in sys.argv[1:] or ["winograd43"]:
+for algo in sys.argv[1:] or ["winograd42"]:
     for wset in ("default",):
         m = cid.load(synth.make_state_dict(wset), device="cuda:0", strict=True)
         m.conv_algo = algo

@@ -1,53 +1,57 @@
-// wino43_kernels.h — 3x3 convolution (+bias, +ReLU, +optional 2x2 max-pool) as Winograd F(4x4,3x3) on the exact-f32 matrix
-// instruction v_mfma_f32_16x16x4_f32 (gfx950): 16 tiles of 4x4 pixels x 64 output channels per workgroup, one row of the
-// transformed 6x6 tile per wave (six waves).
+// wino42_kernels.h — 3x3 convolution (+bias, +ReLU, +optional 2x2 max-pool) as Winograd F(4x2,3x3) — output tiles 4 pixels wide and
+// 2 high — on the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32 (gfx950): 16 tiles x 64 output channels per workgroup, one
+// row of the transformed 4x6 tile per wave (four waves).
 //
-// Same function as the reference's nn.Conv2d(k=3, p=1) + nn.ReLU (+ nn.MaxPool2d(2,2)) stages (backend/app.py:43-77) with 36
-// multiplies per 4x4 output tile and (ci, co) pair instead of 144 (direct) or 64 (F(2x2,3x3), wino64_kernels.h):
-//       M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co]  for the 36 positions xi = (a, b),   V = B^T d B,  U = G g G^T,  Y(4x4) = A^T M A.
-// Interpolation points 0, +-3/4, +-3/2, infinity: every entry of B^T and A^T is a dyadic rational (exact in fp32), and of the
-// point sets tried this one has the smallest error on this network (tools/emulate_f43_winograd.py: 2.8e-6 on the He-gain weights
-// against 1.3e-6 for direct fp32 and 5.8e-6 for the textbook points 0, +-1, +-2; third fed-back iteration 5.6e-6; bound 1e-5).
-// U is computed on the host in double and rounded once (cid_api.hip pack_winograd43_u).
+// Same function as the reference's nn.Conv2d(k=3, p=1) + nn.ReLU (+ nn.MaxPool2d(2,2)) stages (backend/app.py:43-77) with 24
+// multiplies per 8 output pixels and (ci, co) pair: 3 per pixel against 9 (direct) and 4 (F(2x2,3x3), wino64_kernels.h):
+//       M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co]  for the 24 positions xi = (a, b),   V = B2^T d B4,  U = G2 g G4^T,  Y(2x4) = A2^T M A4.
+// Vertically the F(2,3) transform of k_wino64_conv; horizontally F(4,3) at the interpolation points 0, +-3/4, +-3/2, infinity:
+// every entry of B4^T and A4^T is a dyadic rational (exact in fp32), and of the point sets tried this one has the smallest error
+// on this network (tools/emulate_f43_winograd.py, both directions at F(4,3): 2.8e-6 on the He-gain weights against 1.3e-6 for
+// direct fp32 and 5.8e-6 for the textbook points 0, +-1, +-2).  U is computed on the host in double and rounded once
+// (cid_api.hip pack_winograd42_u).
 //
-//   * wave a = row a of B^T d B: 6 positions b x 16 tiles x 64 channels = 24 accumulator tiles of 4 registers.  MFMA row m = tile
+// Why not F(4x4,3x3) (2.25 multiplies per pixel): with a row of the 6x6 tile per wave it needs six waves of ~170 registers; hipcc
+// needs 225-256 for that loop, so only one such workgroup fits a CU and two of its SIMDs carry two waves against one on the
+// others — measured at the speed of F(2x2) (git history: k_wino43_conv).  Four rows fit the 2-waves-per-SIMD budget of k_wino64_conv.
+//
+//   * wave a = row a of B2^T d: 6 positions b x 16 tiles x 64 channels = 24 accumulator tiles of 4 registers.  MFMA row m = tile
 //     m of the workgroup (TC tiles per row, 16/TC rows), k = lane >> 4 = channel 4g + s of the 16-channel chunk at k-step s;
 //     one V value feeds four MFMAs (the four 16-channel groups of the column block).
 //   * raw halo tile in LDS, double-buffered per 16-channel chunk, written by LDS-DMA (out-of-image and pad slots: out-of-range
 //     offset, the range check writes zeros).  Layout [channel group g][row][x mod 4][x div 4] of 16-byte quads: the 16 tiles a
-//     ds_read_b64 service group touches lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 38 / 21 quads).
-//   * V is never stored: per 8-channel unit a lane reads, for each of the 6 patch columns, its (up to) 4 contributing rows
-//     (ds_read_b64: two channels), forms t = sum_r B^T[a][r] d[r] with wave-uniform coefficients, then the six V[b] with the
-//     even/odd split of the +-p rows (14 operations per channel) — all under the previous unit's 48 MFMAs.
+//     ds_read_b64 service group touches lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 quads).
+//   * V is never stored: per 8-channel unit a lane reads, for each of the 6 patch columns, its 2 contributing rows (ds_read_b64:
+//     two channels), forms t = x +- y, and folds it into the six V[b] (even/odd split of the +-p columns) — under the previous
+//     unit's 48 MFMAs, one VALU instruction per MFMA.
 //   * B (U quads: the four channel groups of one (b, k-step)) straight from L2 into a ring of six quads, refilled right after use.
-//   * epilogue: column transform in registers (6 -> 4), the row transform needs all six waves' rows: exchanged through LDS in two
-//     passes (b' pairs), sixteen (channel group, tile quarter) jobs dealt to the six waves; bias, ReLU, optional 2x2 max-pool,
+//   * epilogue: column transform in registers (6 -> 4), the row transform (4 -> 2) needs all four waves' rows: exchanged through
+//     LDS in two passes (b' pairs), sixteen (channel group, tile quarter) jobs, four per wave; bias, ReLU, optional 2x2 max-pool,
 //     64-byte runs per pixel through wave-private staging.
 #pragma once
 #include "wino64_kernels.h"
 
 namespace cid {
 
-constexpr int W43_THREADS = 384;
-
 template <int TC>
-struct W43Geom {
+struct W42Geom {
     static_assert(TC == 16 || TC == 8 || TC == 4, "tiles per workgroup row");
     static constexpr int TRW = 16 / TC;                       // tile rows per workgroup
-    static constexpr int LW = 4 * TC + 2, LH = 4 * TRW + 2;   // raw halo tile, pixels
+    static constexpr int LW = 4 * TC + 2, LH = 2 * TRW + 2;   // raw halo tile, pixels
     static constexpr int QS = TC + 1;                         // quads per (row, x mod 4) run
-    static constexpr int RS = TC == 16 ? 4 * QS : TC == 8 ? 4 * QS + 2 : 4 * QS + 1;   // row stride: tile rows 8 / 4 quads apart (mod 16)
+    static constexpr int RS = TC == 16 ? 68 : TC == 8 ? 36 : 26;   // row stride: tile rows (2 raw rows) 8 / 4 quads apart (mod 16)
+    static_assert(RS >= 4 * QS, "row holds four column planes");
     static constexpr int GS = LH * RS;                        // quads per channel-group plane
     static constexpr int SLOTS = 4 * GS;                      // quads per chunk buffer
-    static constexpr int NROUND = (SLOTS + 63) / 64, RW = (NROUND + 5) / 6;
+    static constexpr int NROUND = (SLOTS + 63) / 64, RW = (NROUND + 3) / 4;
     static constexpr int BUF = NROUND * 64;                   // buffer stride: whole DMA rounds (the last round's spare lanes write zeros)
 };
 
-// Host: LDS quad s of a chunk buffer -> packed (row << 20 | column << 8 | channel group), ~0u = deliver zeros.  Padded to 6*RW rounds.
+// Host: LDS quad s of a chunk buffer -> packed (row << 20 | column << 8 | channel group), ~0u = deliver zeros.  Padded to 4*RW rounds.
 template <int TC>
-inline int wino43_slot_table(unsigned* out /* may be null */) {
-    using Gm = W43Geom<TC>;
-    const int n = 6 * Gm::RW * 64;
+inline int wino42_slot_table(unsigned* out /* may be null */) {
+    using Gm = W42Geom<TC>;
+    const int n = 4 * Gm::RW * 64;
     if (out)
         for (int s = 0; s < n; ++s) {
             unsigned e = ~0u;
@@ -61,24 +65,8 @@ inline int wino43_slot_table(unsigned* out /* may be null */) {
     return n;
 }
 
-// B^T of F(4x4,3x3) at the points 0, 3/4, -3/4, 3/2, -3/2, inf (rows = transformed index, columns = patch row).
-// Row a uses at most four patch rows: {0,2,4} (a=0), {1,2,3,4} (a=1..4), {1,3,5} (a=5).
-__device__ __forceinline__ void w43_row_coeffs(int a, int (&rows)[4], float (&cf)[4]) {
-    if (a == 0) { rows[0] = 0; rows[1] = 2; rows[2] = 4; rows[3] = 4; cf[0] = 1.265625f; cf[1] = -2.8125f; cf[2] = 1.f; cf[3] = 0.f; }
-    else if (a == 5) { rows[0] = 1; rows[1] = 3; rows[2] = 5; rows[3] = 5; cf[0] = 1.265625f; cf[1] = -2.8125f; cf[2] = 1.f; cf[3] = 0.f; }
-    else {
-        rows[0] = 1; rows[1] = 2; rows[2] = 3; rows[3] = 4;
-        const float sg = (a & 1) ? -1.f : 1.f;   // a = 1, 3: the +p rows
-        const bool inner = a <= 2;               // p = 3/4
-        cf[0] = sg * (inner ? 1.6875f : 0.84375f);
-        cf[1] = inner ? -2.25f : -0.5625f;
-        cf[2] = -sg * (inner ? 0.75f : 1.5f);
-        cf[3] = 1.f;
-    }
-}
-
-// A^T of the same points applied to six values: y[i] = sum_j p_j^i m[j] (+ m[5] for i = 3)
-__device__ __forceinline__ void w43_out4(const float (&m)[6], float (&y)[4]) {
+// A4^T of F(4,3) at the points 0, 3/4, -3/4, 3/2, -3/2, inf applied to six values: y[i] = sum_j p_j^i m[j] (+ m[5] for i = 3)
+__device__ __forceinline__ void w42_out4(const float (&m)[6], float (&y)[4]) {
     const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
     y[0] = (m[0] + s12) + s34;
     y[1] = __builtin_fmaf(1.5f, d34, 0.75f * d12);
@@ -87,14 +75,14 @@ __device__ __forceinline__ void w43_out4(const float (&m)[6], float (&y)[4]) {
 }
 
 template <int CIN, int COUT, bool POOL, int TC>
-__global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a) {
-    using Gm = W43Geom<TC>;
+__global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
+    using Gm = W42Geom<TC>;
     constexpr int TRW = Gm::TRW, RS = Gm::RS, QS = Gm::QS, GS = Gm::GS, BUF = Gm::BUF, NROUND = Gm::NROUND, RW = Gm::RW;
     constexpr int NCHUNK = CIN / WK, NU = 2 * NCHUNK;
     constexpr int NB = COUT / WN2;
     static_assert(CIN % WK == 0 && COUT % WN2 == 0, "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
-    constexpr int LDS_SLOTS_K = 4096;            // 64 KiB: 2 raw buffers; later the exchange blocks; later store staging
+    constexpr int LDS_SLOTS_K = 2560;            // 40 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (32 KiB); later store staging
     static_assert(2 * BUF <= LDS_SLOTS_K, "LDS budget");
     __shared__ f32x4 lds[LDS_SLOTS_K];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -103,7 +91,7 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
     int n, ty, tx;
     decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * (4 * TRW), x0 = tx * (4 * TC);
+    const int y0 = ty * (2 * TRW), x0 = tx * (4 * TC);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -114,14 +102,14 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     // ---- LDS-DMA sources (same table format as k_wino64_conv) ----
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
-    // per-lane byte offsets of this wave's DMA rounds, parked in the LDS beyond the two buffers (five registers the main loop
-    // cannot spare; one ds_read_b32 per round instead)
+    // per-lane byte offsets of this wave's DMA rounds, parked in the LDS beyond the two buffers (one ds_read_b32 per round
+    // instead of five registers held across the main loop)
     unsigned* const voff_tab = reinterpret_cast<unsigned*>(lds + 2 * BUF) + wave * (RW * 64) + lane;
-    static_assert(2 * BUF * 16 + 6 * RW * 64 * 4 <= LDS_SLOTS_K * 16, "offset table fits behind the buffers");
+    static_assert(2 * BUF * 16 + 4 * RW * 64 * 4 <= LDS_SLOTS_K * 16, "offset table fits behind the buffers");
     {
         unsigned ent[RW];
 #pragma unroll
-        for (int m = 0; m < RW; ++m) ent[m] = a.slot_tab[(wave + 6 * m) * 64 + lane];
+        for (int m = 0; m < RW; ++m) ent[m] = a.slot_tab[(wave + 4 * m) * 64 + lane];
 #pragma unroll
         for (int m = 0; m < RW; ++m) {
             const unsigned e = ent[m];
@@ -134,8 +122,8 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_round = [&](int buf, int ck, int m) {   // round m of this wave: 64 quads of chunk ck -> LDS buffer `buf`
-        if (wave + 6 * m < NROUND) {                   // wave-uniform
-            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 6 * m) * 64) * 16);
+        if (wave + 4 * m < NROUND) {                   // wave-uniform
+            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
             const int soff = ck * (WK * 4);
             const unsigned vo = voff_tab[m * 64];
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vo), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
@@ -147,21 +135,21 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     };
 
     // ---- U stream of this wave: [nb][unit][a][q = 6*e2 + b][lane][cg]: a unit of one wave is 12 KiB, a quad 1 KiB ----
-    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, CIN * COUT * 36 * 4, 0x00020000);
-    const int ubase = (nb * NU * 6 + wave) * 12288;   // bytes, wave-uniform
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, CIN * COUT * 24 * 4, 0x00020000);
+    const int ubase = (nb * NU * 4 + wave) * 12288;   // bytes, wave-uniform
     const int ulane = lane * 16;
     auto b_load = [&](int gu, int q) -> f32x4 {         // quad q (0..11, in the order the MFMAs use them) of unit gu
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, ubase + gu * (6 * 12288) + q * 1024, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, ubase + gu * (4 * 12288) + q * 1024, 0));
     };
 
-    // ---- row transform of this wave: patch rows and coefficients (wave-uniform) ----
-    int prow[4];
-    float cf[4];
-    w43_row_coeffs(wave, prow, cf);
+    // ---- row transform of this wave (F(2,3), as k_wino64_conv):  t = x + sgn*y over patch rows
+    //   a=0: d0 - d2   a=1: d1 + d2   a=2: d2 - d1   a=3: d1 - d3
+    const int xrow = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
+    const int yrow = (wave == 0 || wave == 1) ? 2 : (wave == 2) ? 1 : 3;
+    const float sgn = (wave == 1) ? 1.f : -1.f;
     const f32x2* lds2 = reinterpret_cast<const f32x2*>(lds);
-    int rbase[4];   // f32x2 index of (channel group g, patch row prow[j] of tile row tr, x = 4 tc) in buffer 0, half 0
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rbase[j] = 2 * (g * GS + (4 * tr + prow[j]) * RS + tc);
+    // f32x2 index of (channel group g, patch rows xrow / yrow of tile row tr, x = 4 tc) in buffer 0, half 0
+    const int xbase = 2 * (g * GS + (2 * tr + xrow) * RS + tc), ybase = 2 * (g * GS + (2 * tr + yrow) * RS + tc);
     auto col_off = [](int c) { return 2 * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, quad tc + c / 4
 
     // ---- prologue ----
@@ -174,18 +162,18 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
 
     f32x4 acc[6][4];   // [position b][channel group cg]; first written by the zero-C MFMAs of unit 0
     float vcur[6][2];
-    f32x2 raw[4];
+    f32x2 rawx, rawy;
     // the next unit's V, column by column: V0 = P0, V1/V2 = E12 +- O12, V3/V4 = E34 +- O34, V5 = P5 (the +-p rows of B^T share
-    // their even and odd parts); a column's t = sum_r B^T[a][r] d[r] is folded into these six as soon as it is formed
+    // their even and odd parts); a column's t = x + sgn*y is folded into these six as soon as it is formed
     float P0[2], E12[2], O12[2], E34[2], O34[2], P5[2];
     auto read_col = [&](int bufhalf, int c) {              // bufhalf = 2 * buf * BUF + s2 (f32x2 units)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) raw[j] = lds2[bufhalf + rbase[j] + col_off(c)];
+        rawx = lds2[bufhalf + xbase + col_off(c)];
+        rawy = lds2[bufhalf + ybase + col_off(c)];
     };
     auto fold_col = [&](int c) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float t = __builtin_fmaf(cf[3], raw[3][e], __builtin_fmaf(cf[2], raw[2][e], __builtin_fmaf(cf[1], raw[1][e], cf[0] * raw[0][e])));
+            const float t = __builtin_fmaf(sgn, rawy[e], rawx[e]);
             if (c == 0) P0[e] = 1.265625f * t;
             if (c == 1) { O12[e] = -1.6875f * t; O34[e] = -0.84375f * t; P5[e] = 1.265625f * t; }
             if (c == 2) { P0[e] = __builtin_fmaf(-2.8125f, t, P0[e]); E12[e] = -2.25f * t; E34[e] = -0.5625f * t; }
@@ -265,7 +253,7 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
     chunk(F{}, F{}, F{}, T{}, NCHUNK - 1);
 
     // ---- output transform ----
-    // step 1, in registers: mp[b'][cg][r] = sum_b A^T[b'][b] acc[b][cg][r]
+    // step 1, in registers: mp[b'][cg][r] = sum_b A4^T[b'][b] acc[b][cg][r]
     float mp[4][16];
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg)
@@ -273,15 +261,14 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
         for (int r = 0; r < 4; ++r) {
             const float mm[6] = {acc[0][cg][r], acc[1][cg][r], acc[2][cg][r], acc[3][cg][r], acc[4][cg][r], acc[5][cg][r]};
             float yy[4];
-            w43_out4(mm, yy);
+            w42_out4(mm, yy);
 #pragma unroll
             for (int bp = 0; bp < 4; ++bp) mp[bp][cg * 4 + r] = yy[bp];
         }
-    // step 2: job j = 4 cg + r (channel group, tile quarter) goes to wave j % 6; every wave posts all sixteen of its row, b' pair by
-    // pair (48 KiB per pass), and sums the six rows of its own jobs:  Y[a'][b'] = sum_a A^T[a'][a] mp_a[b']
+    // step 2: job j = 4 cg + r (channel group, tile quarter) goes to wave j % 4; every wave posts all sixteen of its row, b' pair by
+    // pair (32 KiB per pass), and sums the four rows of its own jobs:  Y[0] = (m0 + m1) + m2,  Y[1] = m1 - (m2 + m3)
     f32x2* ex = reinterpret_cast<f32x2*>(lds);               // block (row a, job j): 64 lanes of f32x2 at (a*16 + j)*64
-    constexpr int NJ = 3;                                    // jobs wave, wave+6, wave+12 (the last only for wave < 4)
-    float Y[NJ][4][4];                                       // [job][a'][b']
+    float Y[4][2][4];                                        // [job][a'][b']
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         __syncthreads();                                     // raw tiles / the previous pass are dead
@@ -289,66 +276,58 @@ __global__ void __launch_bounds__(W43_THREADS, 3) k_wino43_conv(const WinoArgs a
         for (int j = 0; j < 16; ++j) ex[(wave * 16 + j) * 64 + lane] = f32x2{mp[2 * p][j], mp[2 * p + 1][j]};
         __syncthreads();
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int j = wave + 6 * jj;
-            if (j < 16) {
-                f32x2 rowv[6];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = wave + 4 * jj;
+            f32x2 rowv[4];
 #pragma unroll
-                for (int ar = 0; ar < 6; ++ar) rowv[ar] = ex[(ar * 16 + j) * 64 + lane];
+            for (int ar = 0; ar < 4; ++ar) rowv[ar] = ex[(ar * 16 + j) * 64 + lane];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float mm[6] = {rowv[0][e], rowv[1][e], rowv[2][e], rowv[3][e], rowv[4][e], rowv[5][e]};
-                    float yy[4];
-                    w43_out4(mm, yy);
-#pragma unroll
-                    for (int ap = 0; ap < 4; ++ap) Y[jj][ap][2 * p + e] = yy[ap];
-                }
+            for (int e = 0; e < 2; ++e) {
+                Y[jj][0][2 * p + e] = (rowv[0][e] + rowv[1][e]) + rowv[2][e];
+                Y[jj][1][2 * p + e] = rowv[1][e] - (rowv[2][e] + rowv[3][e]);
             }
         }
     }
     __syncthreads();                                         // exchange area is dead: wave-private store staging
-    // step 3: lane (channel n16 of group cg, quarter g) of job (cg, r) holds the 4x4 pixels of tile 4g + r.  Staged as
-    // [tile quarter g][pixel a'*4 + b'][16 channels] (20-float rows, 16 floats between quarters: conflict-free both ways), read
+    // step 3: lane (channel m16 of group cg, quarter g) of job (cg, r) holds the 2x4 pixels of tile 4g + r.  Staged as
+    // [tile quarter g][pixel a'*4 + b'][16 channels] (20-float rows, 16 floats between quarters: conflict-free writes), read
     // back as 16-byte channel quads: four lanes write one pixel's 64 bytes.
-    constexpr int STR = 20, QSTR = 16 * STR + 16;
+    constexpr int STR = 20, QSTR = 8 * STR + 16;
     float* stg = reinterpret_cast<float*>(lds) + wave * (4 * QSTR);
     const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int j = wave + 6 * jj;
-        if (j >= 16) break;
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = wave + 4 * jj;
         const int cg = j >> 2, r = j & 3;
         const int cbase = nb * WN2 + cg * 16;
         const float bias_v = a.bias[cbase + m16];
 #pragma unroll
-        for (int ap = 0; ap < 4; ++ap)
+        for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
             for (int bp = 0; bp < 4; ++bp) stg[g * QSTR + (ap * 4 + bp) * STR + m16] = fmaxf(Y[jj][ap][bp] + bias_v, 0.f);
         wave_lds_fence();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {                     // pass `it` = tile quarter it: 16 pixels x 4 channel quads
-            const int px = lane >> 2, q4 = lane & 3;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + it * QSTR + px * STR + 4 * q4);
-            const int tile = 4 * it + r, ttr = tile / TC, ttc = tile - ttr * TC;
-            const int yy = y0 + 4 * ttr + (px >> 2), xx = x0 + 4 * ttc + (px & 3);
+        for (int it = 0; it < 2; ++it) {                     // pass `it` = tile quarters 2 it, 2 it + 1: 8 pixels x 4 channel quads each
+            const int qt = 2 * it + (lane >> 5), px = (lane >> 2) & 7, q4 = lane & 3;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q4);
+            const int tile = 4 * qt + r, ttr = tile / TC, ttc = tile - ttr * TC;
+            const int yy = y0 + 2 * ttr + (px >> 2), xx = x0 + 4 * ttc + (px & 3);
             if (yy < a.Hs && xx < a.Ws)
                 *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + yy) * a.Ws + xx) * a.out_ps + a.out_coff + cbase + 4 * q4) = v;
         }
         wave_lds_fence();
         if (POOL) {
 #pragma unroll
-            for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
-                    const float mx = fmaxf(fmaxf(Y[jj][2 * pa][2 * pb], Y[jj][2 * pa][2 * pb + 1]), fmaxf(Y[jj][2 * pa + 1][2 * pb], Y[jj][2 * pa + 1][2 * pb + 1]));
-                    stg[g * QSTR + (pa * 2 + pb) * STR + m16] = fmaxf(mx + bias_v, 0.f);
-                }
+            for (int pb = 0; pb < 2; ++pb) {
+                const float mx = fmaxf(fmaxf(Y[jj][0][2 * pb], Y[jj][0][2 * pb + 1]), fmaxf(Y[jj][1][2 * pb], Y[jj][1][2 * pb + 1]));
+                stg[g * QSTR + pb * STR + m16] = fmaxf(mx + bias_v, 0.f);
+            }
             wave_lds_fence();
-            {                                                // 4 quarters x 4 pooled pixels x 4 channel quads = one pass
-                const int it = lane >> 4, px = (lane >> 2) & 3, q4 = lane & 3;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + it * QSTR + px * STR + 4 * q4);
-                const int tile = 4 * it + r, ttr = tile / TC, ttc = tile - ttr * TC;
-                const int py = (y0 >> 1) + 2 * ttr + (px >> 1), pxx = (x0 >> 1) + 2 * ttc + (px & 1);
+            if (lane < 32) {                                 // 4 quarters x 2 pooled pixels x 4 channel quads
+                const int qt = lane >> 3, px = (lane >> 2) & 1, q4 = lane & 3;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q4);
+                const int tile = 4 * qt + r, ttr = tile / TC, ttc = tile - ttr * TC;
+                const int py = (y0 >> 1) + ttr, pxx = (x0 >> 1) + 2 * ttc + px;
                 if (py < Hp && pxx < Wp)
                     *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + pxx) * COUT + cbase + 4 * q4) = v;
             }

@@ -319,13 +319,13 @@ class DenoiseGenerator(nn.Module):
         implicit GEMM) for the eight 3x3 GEMM layers."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
-        return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD43: "winograd43"}.get(a.value, "direct")
+        return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD42: "winograd42"}.get(a.value, "direct")
 
     @conv_algo.setter
     def conv_algo(self, name: str) -> None:
-        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd64": _lib.CID_ALGO_WINOGRAD64, "winograd43": _lib.CID_ALGO_WINOGRAD43}.get(name)
+        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd64": _lib.CID_ALGO_WINOGRAD64, "winograd42": _lib.CID_ALGO_WINOGRAD42}.get(name)
         if algo is None:
-            raise ValueError("conv_algo must be 'direct', 'winograd64' or 'winograd43'")
+            raise ValueError("conv_algo must be 'direct', 'winograd64' or 'winograd42'")
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
     @property

@@ -156,7 +156,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  * (value 1 was round 1's first Winograd kernel, removed: same bits as WINOGRAD64, slower.)
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */
-enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2, CID_ALGO_WINOGRAD43 = 3 };
+enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2, CID_ALGO_WINOGRAD42 = 3 };
 
 /*
  * Storage type of activations and weights between the first and the last kernel (BASELINE configs[4]):

@@ -27,7 +27,7 @@ def _need_gpu():
         pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
 
 
-@pytest.fixture(scope="module", params=["winograd64", "direct", "winograd43"])
+@pytest.fixture(scope="module", params=["winograd64", "direct", "winograd42"])
 def models(request, weight_sets):
     """Both algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(2x2,3x3)
     (the default) and the 9-tap implicit GEMM; and with them both decompositions of the last layer: the row-band kernel
