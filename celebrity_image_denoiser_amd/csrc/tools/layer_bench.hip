@@ -4,6 +4,7 @@
 // and algorithmic TFLOP/s.  ABLATE variants compute wrong results by design (see conv_kernels.h).
 #include "../conv_kernels.h"
 #include "../wino64_kernels.h"
+#include "../wino42_kernels.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,25 @@ static Variant makew64(const char* name, int N, int H, int W, float* in, float* 
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino64_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
 }
 
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE>
+static Variant makew42(const char* name, int N, int H, int W, float* in, float* u, float* bias, float* out, float* pool) {
+    WinoArgs a{};
+    a.in = in; a.u = u; a.bias = bias; a.out = out; a.pool = pool;
+    std::vector<unsigned> h(wino42_slot_table<TC>(nullptr));
+    wino42_slot_table<TC>(h.data());
+    unsigned* tab; CK(hipMalloc(&tab, h.size() * 4));
+    CK(hipMemcpy(tab, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    a.slot_tab = tab;
+    a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
+    constexpr int TRW = 16 / TC;
+    a.tiles_x = (W + 4 * TC - 1) / (4 * TC); a.tiles_y = (H + 2 * TRW - 1) / (2 * TRW);
+    a.tiles_total = N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = (a.tiles_total + 7) / 8;
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
+    const int grid = 8 * a.tiles_per_xcd * (COUT / WN2);
+    const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;   // algorithmic (direct) FLOPs
+    return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }, flops};
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? std::atoi(argv[1]) : 256;
     const int ROUNDS = 7;
@@ -79,6 +99,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> v;
     float* uA = dalloc((size_t)128 * 64 * 16, 0.05f);
     float* uB = dalloc((size_t)256 * 256 * 16, 0.05f);
+    float* u42A = dalloc((size_t)128 * 64 * 24, 0.05f);
+    float* u42B = dalloc((size_t)256 * 256 * 24, 0.05f);
     v.push_back(make<128, 64, 0, 0, 2>("A direct 128->64@128", N, 128, 128, inA, wA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 0>("A wino64 base", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 1>("A wino64 no-dma", N, 128, 128, inA, uA, bA, outA, poolA));
@@ -91,6 +113,15 @@ int main(int argc, char** argv) {
     v.push_back(makew64<128, 64, false, 32, 33>("A wino64 no-dma no-barrier", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 47 + 64>("A wino64 mfma-only no-prologue-dma", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 128>("A wino64 no-dephase", N, 128, 128, inA, uA, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 0>("A wino42 base", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 1>("A wino42 no-dma", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 2>("A wino42 no-B-loads", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 4>("A wino42 no-V-build", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 8>("A wino42 no-epilogue", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 16, 15>("A wino42 mfma-only", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<256, 256, false, 8, 0>("B wino42 base", N, 32, 32, inB, u42B, bB, outB, nullptr));
+    v.push_back(makew42<256, 256, false, 8, 4>("B wino42 no-V-build", N, 32, 32, inB, u42B, bB, outB, nullptr));
+    v.push_back(makew42<256, 256, false, 8, 15>("B wino42 mfma-only", N, 32, 32, inB, u42B, bB, outB, nullptr));
     v.push_back(make<256, 256, 0, 0, 2>("B direct 256->256@32", N, 32, 32, inB, wB, bB, outB, nullptr));
     v.push_back(makew64<256, 256, false, 16, 0>("B wino64 base", N, 32, 32, inB, uB, bB, outB, nullptr));
     v.push_back(makew64<256, 256, false, 16, 15>("B wino64 mfma-only", N, 32, 32, inB, uB, bB, outB, nullptr));
@@ -122,6 +153,24 @@ int main(int argc, char** argv) {
                              h[(size_t)i * 8 + 3], h[(size_t)i * 8 + 6], h[(size_t)i * 8 + 4], h[(size_t)i * 8 + 5]);
         std::fclose(f);
         std::printf("trace written: %d workgroups\n", nwg);
+        {   // the same for the F(4x2) kernel (upconv1.0 shape): phase means only
+            const int nwg3 = 8 * ((N * 2 * 64 + 7) / 8);
+            unsigned long long* tr3; CK(hipMalloc(&tr3, (size_t)nwg3 * 8 * 8)); CK(hipMemset(tr3, 0, (size_t)nwg3 * 8 * 8));
+            Variant w = makew42<128, 64, false, 16, 256>("trace42", N, 128, 128, inA, u42A, bA, outA, reinterpret_cast<float*>(tr3));
+            w.run(s); CK(hipStreamSynchronize(s));
+            CK(hipMemset(tr3, 0, (size_t)nwg3 * 8 * 8));
+            w.run(s); CK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h3((size_t)nwg3 * 8);
+            CK(hipMemcpy(h3.data(), tr3, h3.size() * 8, hipMemcpyDeviceToHost));
+            double pro = 0, mainl = 0, epi = 0, drain = 0; int cnt = 0;
+            for (int i = 0; i < nwg3; ++i) {
+                const unsigned long long* t = &h3[(size_t)i * 8];
+                if (!t[0]) continue;
+                pro += t[1] - t[0]; mainl += t[2] - t[1]; epi += t[3] - t[2]; drain += t[4] - t[3]; ++cnt;
+            }
+            std::printf("wino42 trace (%d workgroups, cycles): prologue %.0f  main loop %.0f (MFMA issue per wave %d)  epilogue %.0f  store drain %.0f\n",
+                        cnt, pro / cnt, mainl / cnt, epi / cnt, drain / cnt, 128 / 8 * 48 * 32);
+        }
         {   // the same for the dominant Winograd launch (upconv1.0 shape)
             const int nwg2 = 8 * ((N * 2 * 64 + 7) / 8);
             unsigned long long* tr2; CK(hipMalloc(&tr2, (size_t)nwg2 * 16 * 8)); CK(hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8));

@@ -74,8 +74,13 @@ __device__ __forceinline__ void w42_out4(const float (&m)[6], float (&y)[4]) {
     y[3] = __builtin_fmaf(3.375f, d34, __builtin_fmaf(0.421875f, d12, m[5]));
 }
 
-template <int CIN, int COUT, bool POOL, int TC>
+// ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue, 2 B quads loaded once,
+// 4 V built once, 8 no epilogue, 256 s_memtime stamps of thread 0 into a.pool (results stay correct, non-POOL layers).
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     using Gm = W42Geom<TC>;
     constexpr int TRW = Gm::TRW, RS = Gm::RS, QS = Gm::QS, GS = Gm::GS, BUF = Gm::BUF, NROUND = Gm::NROUND, RW = Gm::RW;
     constexpr int NCHUNK = CIN / WK, NU = 2 * NCHUNK;
@@ -98,6 +103,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row a
     const int m16 = lane & 15, g = lane >> 4;
     const int tr = m16 / TC, tc = m16 - tr * TC;
+    unsigned long long* trace = (ABLATE & 256) ? reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8 : nullptr;
+    if ((ABLATE & 256) && tid == 0) trace[0] = __builtin_readcyclecounter();
 
     // ---- LDS-DMA sources (same table format as k_wino64_conv) ----
     const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
@@ -206,10 +213,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         constexpr int PAR = decltype(parity_tag)::value ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const bool build = (k == 0) || MORE;
+            const bool build = ((k == 0) || MORE) && !(ABLATE & 4);
             const int nhalf = (k == 0) ? 2 * PAR * BUF + 1 : 2 * (1 - PAR) * BUF;   // the next unit: this buffer's second half, or the other buffer
             const int gu = ck * 2 + k;
-            if (FIRST && k == 0) dma_chunk(1, 1);           // chunk 1 lands under unit 0
+            if (FIRST && k == 0 && !(ABLATE & 1)) dma_chunk(1, 1);   // chunk 1 lands under unit 0
 #pragma unroll
             for (int grp = 0; grp < 12; ++grp) {
                 const int e2 = grp / 6, b = grp - 6 * e2;
@@ -217,7 +224,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                     if (grp >= 1 && grp <= 6) fold_col(grp - 1);
                     if (grp < 6) read_col(nhalf, grp);
                 }
-                if (DMA && k == 1 && grp >= 6 && grp - 6 < RW) dma_round(PAR, ck + 2, grp - 6);
+                if (DMA && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(PAR, ck + 2, grp - 6);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
                     if (FIRST && k == 0 && e2 == 0) {
@@ -228,7 +235,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                     }
                 }
                 // ring slot b: refilled with the quad six uses ahead (the other k-step of this unit, or the next unit's first)
-                if (grp < 6) bq[b] = b_load(gu, grp + 6);
+                if (ABLATE & 2) {}
+                else if (grp < 6) bq[b] = b_load(gu, grp + 6);
                 else if (MORE || k == 0) bq[b] = b_load(gu + 1, grp - 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -243,6 +251,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     };
     using T = std::true_type;
     using F = std::false_type;
+    if ((ABLATE & 256) && tid == 0) trace[1] = __builtin_readcyclecounter();
     chunk(T{}, T{}, T{}, F{}, 0);
     chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
     for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
@@ -252,6 +261,16 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     chunk(F{}, T{}, F{}, F{}, NCHUNK - 2);
     chunk(F{}, F{}, F{}, T{}, NCHUNK - 1);
 
+    if ((ABLATE & 256) && tid == 0) trace[2] = __builtin_readcyclecounter();
+    if (ABLATE & 8) {   // keep the accumulators alive without the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) sum += acc[b][cg][0] + acc[b][cg][1] + acc[b][cg][2] + acc[b][cg][3];
+        if (sum == 123.456f) a.out[tid] = sum;
+        return;
+    }
     // ---- output transform ----
     // step 1, in registers: mp[b'][cg][r] = sum_b A4^T[b'][b] acc[b][cg][r]
     float mp[4][16];
@@ -333,6 +352,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             }
             wave_lds_fence();
         }
+    }
+    if ((ABLATE & 256) && tid == 0) {
+        trace[3] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace[4] = __builtin_readcyclecounter();
     }
 }
 
