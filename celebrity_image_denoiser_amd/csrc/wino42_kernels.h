@@ -19,8 +19,10 @@
 //     m of the workgroup (TC tiles per row, 16/TC rows), k = lane >> 4 = channel 4g + s of the 16-channel chunk at k-step s;
 //     one V value feeds four MFMAs (the four 16-channel groups of the column block).
 //   * raw halo tile in LDS, double-buffered per 16-channel chunk, written by LDS-DMA (out-of-image and pad slots: out-of-range
-//     offset, the range check writes zeros).  Layout [channel group g][row][x mod 4][x div 4] of 16-byte quads: the 16 tiles a
-//     ds_read_b64 service group touches lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 quads).
+//     offset, the range check writes zeros).  Layout [row][x mod 4][x div 4] of pixels, pixel = 4 channel-group quads + 1 pad
+//     quad (as k_wino64_conv: four DMA lanes fetch one pixel's 64 contiguous bytes; with the channel groups in separate planes
+//     every lane of a round touched another 128-byte line and the rounds cost 0.45 of 2.37 ms, tools/layer_bench).  The 16 tiles
+//     of a ds_read_b64 service group lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 pixels).
 //   * V is never stored: per 8-channel unit a lane reads, for each of the 6 patch columns, its 2 contributing rows (ds_read_b64:
 //     two channels), forms t = x +- y, and folds it into the six V[b] (even/odd split of the +-p columns) — under the previous
 //     unit's 48 MFMAs, one VALU instruction per MFMA.
@@ -38,11 +40,10 @@ struct W42Geom {
     static_assert(TC == 16 || TC == 8 || TC == 4, "tiles per workgroup row");
     static constexpr int TRW = 16 / TC;                       // tile rows per workgroup
     static constexpr int LW = 4 * TC + 2, LH = 2 * TRW + 2;   // raw halo tile, pixels
-    static constexpr int QS = TC + 1;                         // quads per (row, x mod 4) run
-    static constexpr int RS = TC == 16 ? 68 : TC == 8 ? 36 : 26;   // row stride: tile rows (2 raw rows) 8 / 4 quads apart (mod 16)
+    static constexpr int QS = TC + 1;                         // pixels per (row, x mod 4) run
+    static constexpr int RS = TC == 16 ? 68 : TC == 8 ? 36 : 26;   // row stride in pixels: tile rows (2 raw rows) 8 / 4 pixels apart (mod 16)
     static_assert(RS >= 4 * QS, "row holds four column planes");
-    static constexpr int GS = LH * RS;                        // quads per channel-group plane
-    static constexpr int SLOTS = 4 * GS;                      // quads per chunk buffer
+    static constexpr int SLOTS = WPS * LH * RS;               // quads per chunk buffer: pixel = 4 channel-group quads + 1 pad
     static constexpr int NROUND = (SLOTS + 63) / 64, RW = (NROUND + 3) / 4;
     static constexpr int BUF = NROUND * 64;                   // buffer stride: whole DMA rounds (the last round's spare lanes write zeros)
 };
@@ -56,9 +57,9 @@ inline int wino42_slot_table(unsigned* out /* may be null */) {
         for (int s = 0; s < n; ++s) {
             unsigned e = ~0u;
             if (s < Gm::SLOTS) {
-                const int g = s / Gm::GS, rem = s % Gm::GS, y = rem / Gm::RS, r2 = rem % Gm::RS, xp = r2 / Gm::QS, q = r2 % Gm::QS;
+                const int p = s / WPS, g = s % WPS, y = p / Gm::RS, r2 = p % Gm::RS, xp = r2 / Gm::QS, q = r2 % Gm::QS;
                 const int x = 4 * q + xp;
-                if (xp < 4 && x < Gm::LW) e = (unsigned)y << 20 | (unsigned)x << 8 | (unsigned)g;
+                if (g < 4 && xp < 4 && x < Gm::LW) e = (unsigned)y << 20 | (unsigned)x << 8 | (unsigned)g;
             }
             out[s] = e;
         }
@@ -82,12 +83,12 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
     using Gm = W42Geom<TC>;
-    constexpr int TRW = Gm::TRW, RS = Gm::RS, QS = Gm::QS, GS = Gm::GS, BUF = Gm::BUF, NROUND = Gm::NROUND, RW = Gm::RW;
+    constexpr int TRW = Gm::TRW, RS = Gm::RS, QS = Gm::QS, BUF = Gm::BUF, NROUND = Gm::NROUND, RW = Gm::RW;
     constexpr int NCHUNK = CIN / WK, NU = 2 * NCHUNK;
     constexpr int NB = COUT / WN2;
     static_assert(CIN % WK == 0 && COUT % WN2 == 0, "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
-    constexpr int LDS_SLOTS_K = 2560;            // 40 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (32 KiB); later store staging
+    constexpr int LDS_SLOTS_K = 3264;            // 51 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (32 KiB); later store staging
     static_assert(2 * BUF <= LDS_SLOTS_K, "LDS budget");
     __shared__ f32x4 lds[LDS_SLOTS_K];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -156,8 +157,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     const float sgn = (wave == 1) ? 1.f : -1.f;
     const f32x2* lds2 = reinterpret_cast<const f32x2*>(lds);
     // f32x2 index of (channel group g, patch rows xrow / yrow of tile row tr, x = 4 tc) in buffer 0, half 0
-    const int xbase = 2 * (g * GS + (2 * tr + xrow) * RS + tc), ybase = 2 * (g * GS + (2 * tr + yrow) * RS + tc);
-    auto col_off = [](int c) { return 2 * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, quad tc + c / 4
+    const int xbase = 2 * (WPS * ((2 * tr + xrow) * RS + tc) + g), ybase = 2 * (WPS * ((2 * tr + yrow) * RS + tc) + g);
+    auto col_off = [](int c) { return 2 * WPS * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, pixel tc + c / 4
 
     // ---- prologue ----
     f32x4 bq[6];
