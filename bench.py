@@ -12,7 +12,7 @@ N=8 — sharded contiguously, weak scaling), inputs already resident in HBM.  Ra
 forward itself has no collective.  Prints one JSON line on rank 0.
 
 Extra objects on that line:
-  roofline      dominant kernel of the forward: FLOPs the matrix pipe EXECUTES per launch (Winograd launches: 16/36 of
+  roofline      dominant kernel of the forward: FLOPs the matrix pipe EXECUTES per launch (Winograd launches: 24/72 or 16/36 of
                 the direct-convolution count) / its mean launch duration from HIP events recorded on the launch stream
                 during the timed steps; peak = gfx950 dense fp32 matrix rate (157.3 TFLOP/s); `frac` <= 1 by
                 construction; `achieved_algorithmic` = direct-convolution FLOPs / the same time
@@ -124,7 +124,7 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
         roof = {"bound": "mfma", "achieved": d["tflops_executed"], "peak": peak_tf, "unit": "TFLOP/s", "frac": d["frac"],
                 "traffic": traffic, "achieved_algorithmic": d["tflops_algorithmic"]}
         if "wino" in d["kernel"]:
-            roof["note"] = ("achieved = FLOPs the matrix pipe executes (Winograd F(2x2,3x3): 16/36 of the direct-convolution count) / "
+            roof["note"] = ("achieved = FLOPs the matrix pipe executes (Winograd F(4x2,3x3): 24/72, F(2x2,3x3): 16/36 of the direct-convolution count) / "
                             "mean launch time; achieved_algorithmic = direct-convolution FLOPs (SURVEY 8a) / the same time")
     else:
         roof = {"bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["frac"], "traffic": traffic}
@@ -187,9 +187,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--weights", default="default", choices=["default", "hot"])
-    ap.add_argument("--algo", default="winograd64", choices=["winograd64", "winograd42", "direct"],
-                    help="algorithm of the eight 3x3 GEMM layers (all fp32): winograd64 = Winograd F(2x2,3x3), 64 output channels per "
-                         "workgroup (default); direct = 9-tap implicit GEMM")
+    ap.add_argument("--algo", default="winograd42", choices=["winograd42", "winograd64", "direct"],
+                    help="algorithm of the eight 3x3 GEMM layers (all fp32): winograd42 = Winograd F(4x2,3x3) (default); "
+                         "winograd64 = Winograd F(2x2,3x3); direct = 9-tap implicit GEMM")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 = the reference's arithmetic (the headline metric); f16 = BASELINE configs[4] (half storage, "
                          "fp16 MFMA with fp32 accumulators) — a different numerical contract, reported for that config only")

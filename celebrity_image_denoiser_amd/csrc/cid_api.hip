@@ -46,6 +46,11 @@ const char* kWino64KernelNames[NL] = {
     "k_wino64_conv<128, 256, false,", "k_wino64_conv<256, 256, false,", nullptr, "k_wino64_conv<256, 128, false,",
     "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
 };
+const char* kWino42KernelNames[NL] = {   // upconv1[0] keeps the F(2x2) kernel: its epilogue carries the fused last-layer contraction
+    nullptr, "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
+    "k_wino42_conv<128, 256, false,", "k_wino42_conv<256, 256, false,", nullptr, "k_wino42_conv<256, 128, false,",
+    "k_wino42_conv<128, 128, false,", nullptr, "k_wino42_conv<128, 64, false,", nullptr,
+};
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline unsigned long long cdiv_ull(unsigned long long a, unsigned long long b) { return (a + b - 1) / b; }
@@ -256,7 +261,7 @@ struct cid_handle_s {
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
     int tail_algo = CID_TAIL_FUSED;    // last layer: see cid_set_tail_algo
-    int algo = CID_ALGO_WINOGRAD64;    // 3x3 GEMM layers: CID_ALGO_DIRECT (9-tap implicit GEMM) or Winograd F(2x2,3x3)
+    int algo = CID_ALGO_WINOGRAD42;    // 3x3 GEMM layers: Winograd F(4x2,3x3) (default), Winograd F(2x2,3x3) or CID_ALGO_DIRECT (9-tap implicit GEMM)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
     cid_handle_s() : staging(kBlob.total, 0.f) {
@@ -781,7 +786,8 @@ const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
-    if (h && h->algo == CID_ALGO_WINOGRAD64 && kWino64KernelNames[i]) return kWino64KernelNames[i];
+    if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i] && !(i == 10 && fused_tail_active(h))) return kWino42KernelNames[i];
+    if (h && h->algo != CID_ALGO_DIRECT && kWino64KernelNames[i]) return kWino64KernelNames[i];
     return kKernelNames[i];
 }
 

@@ -315,8 +315,8 @@ class DenoiseGenerator(nn.Module):
 
     @property
     def conv_algo(self) -> str:
-        """"winograd64" (default; Winograd F(2x2,3x3) on MFMA, 64 output channels per workgroup) or "direct" (9-tap
-        implicit GEMM) for the eight 3x3 GEMM layers."""
+        """Algorithm of the eight 3x3 GEMM layers: "winograd42" (default; Winograd F(4x2,3x3) on MFMA, 3 multiplies per
+        output pixel and channel pair), "winograd64" (Winograd F(2x2,3x3), 4 multiplies) or "direct" (9-tap implicit GEMM, 9)."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
         return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD42: "winograd42"}.get(a.value, "direct")
@@ -377,7 +377,7 @@ class DenoiseGenerator(nn.Module):
 def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
     """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes, executed flops)] of one forward, per LAUNCH under
     `model`'s configuration (direct kernels, unfused, if no model is given).  Algorithmic = the direct-convolution count of
-    the reference layer(s) the launch computes; executed = what its MFMAs issue: the Winograd F(2x2,3x3) kernels run 16/36 of
+    the reference layer(s) the launch computes; executed = what its MFMAs issue: the Winograd kernels run 24/72 (F(4x2,3x3)) or 16/36 (F(2x2,3x3)) of
     their 3x3 layer's multiplies (a fused-in contraction of the next layer is executed as it stands)."""
     L = _lib.lib()
     rows = []
@@ -388,6 +388,6 @@ def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
         _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f0), ctypes.byref(b0)))
         kern = L.cid_launch_kernel(handle, i).decode()
         own = min(f.value, f0.value)                       # the launch's own layer (0 for a launch that only sums)
-        executed = own * (16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
+        executed = own * (24.0 / 72.0 if "wino42" in kern else 16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
         rows.append((L.cid_launch_name(i).decode(), kern, f.value, b.value, executed))
     return rows

@@ -27,11 +27,11 @@ def _need_gpu():
         pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
 
 
-@pytest.fixture(scope="module", params=["winograd64", "direct", "winograd42"])
+@pytest.fixture(scope="module", params=["winograd42", "winograd64", "direct"])
 def models(request, weight_sets):
-    """Both algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(2x2,3x3)
-    (the default) and the 9-tap implicit GEMM; and with them both decompositions of the last layer: the row-band kernel
-    (default) and the tiled kernel (which also serves images wider than 128 pixels under the default)."""
+    """All three algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(4x2,3x3) (the default),
+    Winograd F(2x2,3x3) and the 9-tap implicit GEMM; and with them both decompositions of the last layer: fused into
+    upconv1[0]'s epilogue (default) and the tiled kernel."""
     _need_gpu()
     import celebrity_image_denoiser_amd as cid
 
@@ -346,7 +346,7 @@ def test_winograd_and_direct_agree(weight_sets):
 
     x, _, _ = synth.make_batch(4, 128, 128, first_index=1300)
     m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
-    assert m.conv_algo == "winograd64"   # the default
+    assert m.conv_algo == "winograd42"   # the default
     yw = _run(m, x)
     m.conv_algo = "direct"
     yd = _run(m, x)
