@@ -27,9 +27,9 @@
 //     two channels), forms t = x +- y, and folds it into the six V[b] (even/odd split of the +-p columns) — under the previous
 //     unit's 48 MFMAs, one VALU instruction per MFMA.
 //   * B (U quads: the four channel groups of one (b, k-step)) straight from L2 into a ring of six quads, refilled right after use.
-//   * epilogue: column transform in registers (6 -> 4), the row transform (4 -> 2) needs all four waves' rows: exchanged through
-//     LDS in two passes (b' pairs), sixteen (channel group, tile quarter) jobs, four per wave; bias, ReLU, optional 2x2 max-pool,
-//     64-byte runs per pixel through wave-private staging.
+//   * epilogue: column transform in registers (6 -> 4); the row transform (4 -> 2) needs all four waves' rows: wave w takes the
+//     tile quarter r = w (tiles 4g + w, all 64 channels), the other three rows come through LDS (48 KiB, one pass); bias, ReLU,
+//     optional 2x2 max-pool, whole 256-byte pixels through wave-private staging.
 #pragma once
 #include "wino64_kernels.h"
 
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     constexpr int NB = COUT / WN2;
     static_assert(CIN % WK == 0 && COUT % WN2 == 0, "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
-    constexpr int LDS_SLOTS_K = 3264;            // 51 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (32 KiB); later store staging
+    constexpr int LDS_SLOTS_K = 3264;            // 51 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (48 KiB); later store staging
     static_assert(2 * BUF <= LDS_SLOTS_K, "LDS budget");
     __shared__ f32x4 lds[LDS_SLOTS_K];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -273,8 +273,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         return;
     }
     // ---- output transform ----
-    // step 1, in registers: mp[b'][cg][r] = sum_b A4^T[b'][b] acc[b][cg][r]
-    float mp[4][16];
+    // Wave w finishes tile quarter r = w: the tiles 4g + w (g = lane >> 4) for all four channel groups.  Its bias values are
+    // requested here; the column transform and the exchange cover their latency.
+    float bias_v[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[nb * WN2 + cg * 16 + m16];
+    // step 1, in registers: mp[cg][r] = (b' = 0..3) = sum_b A4^T[b'][b] acc[b][cg][r]
+    f32x4 mp[4][4];
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -282,77 +287,81 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             const float mm[6] = {acc[0][cg][r], acc[1][cg][r], acc[2][cg][r], acc[3][cg][r], acc[4][cg][r], acc[5][cg][r]};
             float yy[4];
             w42_out4(mm, yy);
-#pragma unroll
-            for (int bp = 0; bp < 4; ++bp) mp[bp][cg * 4 + r] = yy[bp];
+            mp[cg][r] = f32x4{yy[0], yy[1], yy[2], yy[3]};
         }
-    // step 2: job j = 4 cg + r (channel group, tile quarter) goes to wave j % 4; every wave posts all sixteen of its row, b' pair by
-    // pair (32 KiB per pass), and sums the four rows of its own jobs:  Y[0] = (m0 + m1) + m2,  Y[1] = m1 - (m2 + m3)
-    f32x2* ex = reinterpret_cast<f32x2*>(lds);               // block (row a, job j): 64 lanes of f32x2 at (a*16 + j)*64
-    float Y[4][2][4];                                        // [job][a'][b']
+    // step 2: the rows of the three other waves through LDS — block (row a, consumer w != a, cg): 64 lanes of 16 bytes (48 KiB in all) —
+    //   Y[0] = (m0 + m1) + m2,  Y[1] = m1 - (m2 + m3)   (the F(2,3) output transform of k_wino64_conv, same order)
+    auto epilogue = [&](auto wave_tag) {
+        constexpr int W = decltype(wave_tag)::value;
+        __syncthreads();                                     // raw tiles are dead: LDS becomes the exchange area
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        __syncthreads();                                     // raw tiles / the previous pass are dead
+        for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) ex[(wave * 16 + j) * 64 + lane] = f32x2{mp[2 * p][j], mp[2 * p + 1][j]};
+            for (int r = 0; r < 4; ++r)
+                if (r != W) lds[((W * 3 + (r - (r > W ? 1 : 0))) * 4 + cg) * 64 + lane] = mp[cg][r];
         __syncthreads();
+        f32x4 Y[4][2];                                       // [cg][a'] = the four b' of output row a'
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = wave + 4 * jj;
-            f32x2 rowv[4];
+        for (int cg = 0; cg < 4; ++cg) {
+            f32x4 m[4];
 #pragma unroll
-            for (int ar = 0; ar < 4; ++ar) rowv[ar] = ex[(ar * 16 + j) * 64 + lane];
+            for (int ar = 0; ar < 4; ++ar) m[ar] = (ar == W) ? mp[cg][W] : lds[((ar * 3 + (W - (W > ar ? 1 : 0))) * 4 + cg) * 64 + lane];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                Y[jj][0][2 * p + e] = (rowv[0][e] + rowv[1][e]) + rowv[2][e];
-                Y[jj][1][2 * p + e] = rowv[1][e] - (rowv[2][e] + rowv[3][e]);
+            for (int e = 0; e < 4; ++e) {
+                Y[cg][0][e] = (m[0][e] + m[1][e]) + m[2][e];
+                Y[cg][1][e] = m[1][e] - (m[2][e] + m[3][e]);
             }
         }
-    }
-    __syncthreads();                                         // exchange area is dead: wave-private store staging
-    // step 3: lane (channel m16 of group cg, quarter g) of job (cg, r) holds the 2x4 pixels of tile 4g + r.  Staged as
-    // [tile quarter g][pixel a'*4 + b'][16 channels] (20-float rows, 16 floats between quarters: conflict-free writes), read
-    // back as 16-byte channel quads: four lanes write one pixel's 64 bytes.
-    constexpr int STR = 20, QSTR = 8 * STR + 16;
-    float* stg = reinterpret_cast<float*>(lds) + wave * (4 * QSTR);
-    const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        __syncthreads();                                     // exchange area is dead: wave-private store staging
+        // step 3: lane (channel m16 of every group cg, quarter g) holds the 2x4 pixels of tile 4g + W.  Staged as
+        // [quarter g][pixel a'*4 + b'][64 channels] (68-float rows, 16 floats between quarters: conflict-free writes), read back
+        // as 16-byte channel quads: sixteen lanes write one pixel's 256 bytes.
+        constexpr int STR = 68, QSTR = 8 * STR + 16;
+        float* stg = reinterpret_cast<float*>(lds) + W * (4 * QSTR);
+        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        const int cbase = nb * WN2;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = wave + 4 * jj;
-        const int cg = j >> 2, r = j & 3;
-        const int cbase = nb * WN2 + cg * 16;
-        const float bias_v = a.bias[cbase + m16];
+        for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
-        for (int ap = 0; ap < 2; ++ap)
+            for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
-            for (int bp = 0; bp < 4; ++bp) stg[g * QSTR + (ap * 4 + bp) * STR + m16] = fmaxf(Y[jj][ap][bp] + bias_v, 0.f);
+                for (int bp = 0; bp < 4; ++bp) stg[g * QSTR + (ap * 4 + bp) * STR + cg * 16 + m16] = fmaxf(Y[cg][ap][bp] + bias_v[cg], 0.f);
         wave_lds_fence();
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {                     // pass `it` = tile quarters 2 it, 2 it + 1: 8 pixels x 4 channel quads each
-            const int qt = 2 * it + (lane >> 5), px = (lane >> 2) & 7, q4 = lane & 3;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q4);
-            const int tile = 4 * qt + r, ttr = tile / TC, ttc = tile - ttr * TC;
+        for (int it = 0; it < 8; ++it) {                     // pass `it`: 4 pixels x 16 channel quads
+            const int pe = it * 4 + (lane >> 4), qt = pe >> 3, px = pe & 7, q16 = lane & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q16);
+            const int tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;
             const int yy = y0 + 2 * ttr + (px >> 2), xx = x0 + 4 * ttc + (px & 3);
             if (yy < a.Hs && xx < a.Ws)
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + yy) * a.Ws + xx) * a.out_ps + a.out_coff + cbase + 4 * q4) = v;
+                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + yy) * a.Ws + xx) * a.out_ps + a.out_coff + cbase + 4 * q16) = v;
         }
-        wave_lds_fence();
         if (POOL) {
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const float mx = fmaxf(fmaxf(Y[jj][0][2 * pb], Y[jj][0][2 * pb + 1]), fmaxf(Y[jj][1][2 * pb], Y[jj][1][2 * pb + 1]));
-                stg[g * QSTR + pb * STR + m16] = fmaxf(mx + bias_v, 0.f);
-            }
             wave_lds_fence();
-            if (lane < 32) {                                 // 4 quarters x 2 pooled pixels x 4 channel quads
-                const int qt = lane >> 3, px = (lane >> 2) & 1, q4 = lane & 3;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q4);
-                const int tile = 4 * qt + r, ttr = tile / TC, ttc = tile - ttr * TC;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const float mx = fmaxf(fmaxf(Y[cg][0][2 * pb], Y[cg][0][2 * pb + 1]), fmaxf(Y[cg][1][2 * pb], Y[cg][1][2 * pb + 1]));
+                    stg[g * QSTR + pb * STR + cg * 16 + m16] = fmaxf(mx + bias_v[cg], 0.f);
+                }
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {                 // 4 quarters x 2 pooled pixels x 16 channel quads
+                const int pe = it * 4 + (lane >> 4), qt = pe >> 1, px = pe & 1, q16 = lane & 15;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q16);
+                const int tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;
                 const int py = (y0 >> 1) + ttr, pxx = (x0 >> 1) + 2 * ttc + px;
                 if (py < Hp && pxx < Wp)
-                    *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + pxx) * COUT + cbase + 4 * q4) = v;
+                    *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + pxx) * COUT + cbase + 4 * q16) = v;
             }
-            wave_lds_fence();
         }
+    };
+    switch (wave) {   // four code versions: "is this my own row" is a compile-time fact
+        case 0: epilogue(std::integral_constant<int, 0>{}); break;
+        case 1: epilogue(std::integral_constant<int, 1>{}); break;
+        case 2: epilogue(std::integral_constant<int, 2>{}); break;
+        default: epilogue(std::integral_constant<int, 3>{}); break;
     }
     if ((ABLATE & 256) && tid == 0) {
         trace[3] = __builtin_readcyclecounter();
