@@ -46,7 +46,7 @@ const char* kWino64KernelNames[NL] = {
     "k_wino64_conv<128, 256, false,", "k_wino64_conv<256, 256, false,", nullptr, "k_wino64_conv<256, 128, false,",
     "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
 };
-const char* kWino42KernelNames[NL] = {   // upconv1[0] keeps the F(2x2) kernel: its epilogue carries the fused last-layer contraction
+const char* kWino42KernelNames[NL] = {
     nullptr, "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
     "k_wino42_conv<128, 256, false,", "k_wino42_conv<256, 256, false,", nullptr, "k_wino42_conv<256, 128, false,",
     "k_wino42_conv<128, 128, false,", nullptr, "k_wino42_conv<128, 64, false,", nullptr,
@@ -353,7 +353,18 @@ hipError_t launch_wino64_z_tc(hipStream_t s, const WinoArgs& base) {
     hipLaunchKernelGGL((k_wino64_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_upconv1_0_z(hipStream_t s, const float* blob, const float* in, int Hc, int Wc, float* zout, int N) {
+template <int TC>
+hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
+    WinoArgs a = base;
+    constexpr int TRW = 16 / TC;
+    a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab42_off[tab]);
+    a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
+    a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
+    a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
+    hipLaunchKernelGGL((k_wino42_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const float* in, int Hc, int Wc, float* zout, int N) {
     WinoArgs a;
     a.in = in; a.u = blob + kBlob.u_off[10]; a.bias = blob + kBlob.b_off[10];
     a.out = nullptr; a.pool = nullptr; a.zw = blob + kBlob.w_off[11]; a.zout = zout;
@@ -361,6 +372,12 @@ hipError_t launch_upconv1_0_z(hipStream_t s, const float* blob, const float* in,
     a.out_ps = 64; a.out_coff = 0;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
+    if (algo == CID_ALGO_WINOGRAD42) {
+        a.u = blob + kBlob.u42_off[10];
+        if (Wc > 32) return launch_wino42_z_tc<16>(s, a, blob, 0);
+        if (Wc > 16) return launch_wino42_z_tc<8>(s, a, blob, 1);
+        return launch_wino42_z_tc<4>(s, a, blob, 2);
+    }
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
     return Wc > 32 ? launch_wino64_z_tc<32>(s, a) : launch_wino64_z_tc<16>(s, a);
 }
@@ -527,7 +544,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     const bool fused_tail = fused_tail_active(h);
     if (fused_tail) {
         // upconv1[0] + ReLU, with upconv1[2]'s channel contraction in its epilogue: z planes into the t4 region     app.py:75-77
-        STEP(launch_upconv1_0_z(s, blob, B[CAT1], d.Hu1, d.Wu1, B[T4], N));
+        STEP(launch_upconv1_0_z(h->algo, s, blob, B[CAT1], d.Hu1, d.Wu1, B[T4], N));
         // the nine-tap shifted sum + bias + tanh, -> NCHW out                              app.py:77,103
         STEP(launch_tail_z(s, B[T4], blob + kBlob.b_off[11], out, N, d.Hu1, d.Wu1, out_fmt == CID_FMT_U8_NHWC));
     } else {
@@ -786,7 +803,7 @@ const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
-    if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i] && !(i == 10 && fused_tail_active(h))) return kWino42KernelNames[i];
+    if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];
     if (h && h->algo != CID_ALGO_DIRECT && kWino64KernelNames[i]) return kWino64KernelNames[i];
     return kKernelNames[i];
 }

@@ -77,8 +77,9 @@ __device__ __forceinline__ void w42_out4(const float (&m)[6], float (&y)[4]) {
 
 // ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue, 2 B quads loaded once,
 // 4 V built once, 8 no epilogue, 256 s_memtime stamps of thread 0 into a.pool (results stay correct, non-POOL layers).
-template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0>
+template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0, bool ZOUT = false>
 __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
+    static_assert(!ZOUT || (COUT == 64 && !POOL), "ZOUT contracts exactly the 64 channels of the workgroup's column block");
 #ifndef CID_EXPERIMENTS
     static_assert(ABLATE == 0, "ablation/trace variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
@@ -327,6 +328,46 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 #pragma unroll
                 for (int bp = 0; bp < 4; ++bp) stg[g * QSTR + (ap * 4 + bp) * STR + cg * 16 + m16] = fmaxf(Y[cg][ap][bp] + bias_v[cg], 0.f);
         wave_lds_fence();
+        if constexpr (ZOUT) {
+            // upconv1[0] as the producer of the last layer's input (see k_wino64_conv): the wave's staging holds relu(y) of its 32
+            // pixels x 64 channels; z[p][3*tap + co] = sum_ci relu(y)[p][ci] * W2[co][ci][tap] is a [32 x 64] x [64 x 32 (27 used)]
+            // product, 32 MFMAs of 32x32x2, stored as 27 planes [N, 27, H, W].  MFMA row i = pixel (quarter i >> 3, i & 7).
+            const int i32 = lane & 31, h = lane >> 5;
+            f32x4 zb[2][4];
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) zb[ck][gq] = reinterpret_cast<const f32x4*>(a.zw)[(ck * 4 + gq) * 64 + lane];
+            f32x16 zacc;
+            const float* src = stg + (i32 >> 3) * QSTR + (i32 & 7) * STR + 4 * h;
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(src + 32 * ck + 8 * gq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ck == 0 && gq == 0 && e == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], zb[ck][gq][e], zero, 0, 0, 0);
+                        } else {
+                            zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], zb[ck][gq][e], zacc, 0, 0, 0);
+                        }
+                    }
+                }
+            // lane (column j = i32, half h) holds z[pixel (r&3) + 8*(r>>2) + 4*h][j]: registers 4q..4q+3 are the four pixels b' = 0..3
+            // of row a' = h of tile 4q + W — one 16-byte store each into plane j
+            if (i32 < 27) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;
+                    const int yy = y0 + 2 * ttr + h, xx = x0 + 4 * ttc;
+                    if (yy < a.Hs && xx < a.Ws)
+                        *reinterpret_cast<f32x4*>(a.zout + (((size_t)n * 27 + i32) * a.Hs + yy) * a.Ws + xx) = f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {                     // pass `it`: 4 pixels x 16 channel quads
             const int pe = it * 4 + (lane >> 4), qt = pe >> 3, px = pe & 7, q16 = lane & 15;
