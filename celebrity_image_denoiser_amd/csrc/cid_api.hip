@@ -69,7 +69,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[3], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -96,9 +96,8 @@ struct BlobLayout {
             u42_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + (size_t)kLayers[l].cin * kLayers[l].cout * 24, 64);
         }
-        tab42_off[0] = o; o = align_up(o + wino42_slot_table<16>(nullptr), 64);   // its LDS slot tables, TC = 16, 8, 4
-        tab42_off[1] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);
-        tab42_off[2] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
+        tab42_off[0] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);   // its LDS slot tables, TC = 8 and 4
+        tab42_off[1] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
         total = o;
     }
 };
@@ -268,9 +267,8 @@ struct cid_handle_s {
         std::memset(have, 0, sizeof(have));
         wino_slot_table(32, 1, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[0]));
         wino_slot_table(16, 2, reinterpret_cast<unsigned*>(staging.data() + kBlob.tab_off[1]));
-        wino42_slot_table<16>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[0]));
-        wino42_slot_table<8>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[1]));
-        wino42_slot_table<4>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[2]));
+        wino42_slot_table<8>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[0]));
+        wino42_slot_table<4>(reinterpret_cast<unsigned*>(staging.data() + kBlob.tab42_off[1]));
     }
 };
 
@@ -374,9 +372,8 @@ hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const 
     a.rcp_x = a.rcp_xy = 0;
     if (algo == CID_ALGO_WINOGRAD42) {
         a.u = blob + kBlob.u42_off[10];
-        if (Wc > 32) return launch_wino42_z_tc<16>(s, a, blob, 0);
-        if (Wc > 16) return launch_wino42_z_tc<8>(s, a, blob, 1);
-        return launch_wino42_z_tc<4>(s, a, blob, 2);
+        if (Wc > 16) return launch_wino42_z_tc<8>(s, a, blob, 0);
+        return launch_wino42_z_tc<4>(s, a, blob, 1);
     }
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
     return Wc > 32 ? launch_wino64_z_tc<32>(s, a) : launch_wino64_z_tc<16>(s, a);
@@ -415,11 +412,11 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0;
-    if (algo == CID_ALGO_WINOGRAD42) {   // 16 tiles of 4x2 pixels per workgroup: 16 x 1, 8 x 2 or 4 x 4 by the width of the rows
+    if (algo == CID_ALGO_WINOGRAD42) {   // 16 tiles of 4x2 pixels per workgroup: 8 x 2 (32x4 pixels), or 4 x 4 (16x8) for rows of 16 pixels or fewer.
+        // 16 x 1 (64x2 pixels) fetches 4 input rows for 2 of output: same-box 24.4k images/s against 24.8k (8 x 2) and 24.7k (4 x 4 everywhere)
         a.u = blob + kBlob.u42_off[layer];
-        if (Wc > 32) return launch_wino42_tc<CIN, COUT, MODE == 1, 16>(s, a, blob, 0);
-        if (Wc > 16) return launch_wino42_tc<CIN, COUT, MODE == 1, 8>(s, a, blob, 1);
-        return launch_wino42_tc<CIN, COUT, MODE == 1, 4>(s, a, blob, 2);
+        if (Wc > 16) return launch_wino42_tc<CIN, COUT, MODE == 1, 8>(s, a, blob, 0);
+        return launch_wino42_tc<CIN, COUT, MODE == 1, 4>(s, a, blob, 1);
     }
     // 32 tile-columns (64 pixels) per workgroup when the rows are wide enough, else 16 x 2 tile-rows
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
