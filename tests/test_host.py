@@ -184,3 +184,30 @@ def test_host_pipeline_refuses_cpu_model():
         cid.HostPipeline(cid.DenoiseGenerator())
     with pytest.raises(ValueError):
         cid.HostPipeline(cid.DenoiseGenerator(), depth=1)
+
+
+def test_winograd_f4x2_transform_constants():
+    """The constants k_wino42_conv hard-codes (csrc/wino42_kernels.h: B4^T rows, A4^T in w42_out4, G4 in pack_winograd42_u;
+    interpolation points 0, +-3/4, +-3/2, inf) and the F(2,3) matrices of the vertical direction compute a 3x3 correlation
+    exactly: Y(2x4) = A2^T [ (G2 g G4^T) . (B2^T d B4) ] A4 against the direct sum, in float64, for random g and d.  Every
+    entry of B4^T and A4^T is a dyadic rational, i.e. exact in fp32 (the kernel's transforms add no coefficient rounding)."""
+    B4t = np.array([[81 / 64, 0, -45 / 16, 0, 1, 0], [0, -27 / 16, -9 / 4, 3 / 4, 1, 0], [0, 27 / 16, -9 / 4, -3 / 4, 1, 0],
+                    [0, -27 / 32, -9 / 16, 3 / 2, 1, 0], [0, 27 / 32, -9 / 16, -3 / 2, 1, 0], [0, 81 / 64, 0, -45 / 16, 0, 1]])
+    A4t = np.array([[1, 1, 1, 1, 1, 0], [0, 3 / 4, -3 / 4, 3 / 2, -3 / 2, 0], [0, 9 / 16, 9 / 16, 9 / 4, 9 / 4, 0],
+                    [0, 27 / 64, -27 / 64, 27 / 8, -27 / 8, 1]])
+    G4 = np.array([[64 / 81, 0, 0], [-128 / 243, -32 / 81, -8 / 27], [-128 / 243, 32 / 81, -8 / 27],
+                   [32 / 243, 16 / 81, 8 / 27], [32 / 243, -16 / 81, 8 / 27], [0, 0, 1]])
+    B2t = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    A2t = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    for m in (B4t, A4t):
+        assert np.array_equal(m.astype(np.float32).astype(np.float64), m)      # exact in fp32
+        assert np.array_equal(m * 64, np.round(m * 64))                        # dyadic, denominators <= 64
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        g, d = rng.standard_normal((3, 3)), rng.standard_normal((4, 6))        # patch: 4 rows x 6 columns -> 2 x 4 outputs
+        U = G2 @ g @ G4.T
+        V = B2t @ d @ B4t.T
+        Y = A2t @ (U * V) @ A4t.T
+        ref = np.array([[(d[y:y + 3, x:x + 3] * g).sum() for x in range(4)] for y in range(2)])
+        assert np.abs(Y - ref).max() < 1e-12
