@@ -150,9 +150,11 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
 
 /*
  * Algorithm of the eight GEMM-shaped 3x3 convolutions (down1[2] ... upconv1[0]); head, tail and the
- * transposed convolutions are unaffected.  Both compute the reference's nn.Conv2d(k=3,p=1) in fp32:
- *   CID_ALGO_DIRECT     implicit GEMM, 9 taps (36 multiplies per 2x2 outputs and (ci,co))
- *   CID_ALGO_WINOGRAD64 Winograd F(2x2,3x3) (16 multiplies), 64 output channels per workgroup: the default
+ * transposed convolutions are unaffected.  All compute the reference's nn.Conv2d(k=3,p=1) in fp32 (exact-fp32 MFMA):
+ *   CID_ALGO_DIRECT     implicit GEMM, 9 taps: 9 multiplies per output pixel and (ci,co)
+ *   CID_ALGO_WINOGRAD64 Winograd F(2x2,3x3): 4 multiplies per pixel (round 1's default)
+ *   CID_ALGO_WINOGRAD42 Winograd F(4x2,3x3), tiles 4 wide x 2 high, interpolation points 0, +-3/4, +-3/2, inf: 3 multiplies
+ *                       per pixel: the default
  * (value 1 was round 1's first Winograd kernel, removed: same bits as WINOGRAD64, slower.)
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */
@@ -175,7 +177,7 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
  * How the last layer (upconv1[2] = Conv2d(64,3,3,p=1) + tanh, backend/app.py:77,103) runs on the fp32 path; same function:
  *   CID_TAIL_FUSED  (default) its 64 -> 27 (tap x channel) contraction runs in the epilogue of upconv1[0]'s kernel, on the
  *                   tile still in LDS; the last launch is the nine-tap shifted sum + bias + tanh over 27 planes.  Needs
- *                   CID_ALGO_WINOGRAD64 and CID_DTYPE_F32; otherwise the handle behaves as CID_TAIL_BANDS.
+ *                   a Winograd algorithm and CID_DTYPE_F32; otherwise the handle behaves as CID_TAIL_BANDS.
  *   CID_TAIL_BANDS  separate kernel: a workgroup slides down a band of rows, the contraction is computed once per pixel
  *                   (images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
  *   CID_TAIL_TILES  separate kernel: 8x32-pixel tiles, the contraction is computed over each tile's halo (round 1's kernel)
