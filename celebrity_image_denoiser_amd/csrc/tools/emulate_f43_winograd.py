@@ -2,7 +2,7 @@
 transform matrices of Lavin & Gray (interpolation points 0, +-1, +-2, inf), U = G g G^T in double rounded once to fp32, V, M and the output
 transform in fp32; compared with the float64 forward and with the fp32 oracle, final output and every stage."""
 import sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..', '..'))
 from celebrity_image_denoiser_amd import synth
 torch.set_num_threads(8)
 G = torch.tensor([[1/4, 0, 0], [-1/6, -1/6, -1/6], [-1/6, 1/6, -1/6], [1/24, 1/12, 1/6], [1/24, -1/12, 1/6], [0, 0, 1]], dtype=torch.float64)
