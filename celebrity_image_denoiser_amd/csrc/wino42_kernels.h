@@ -24,8 +24,8 @@
 //     every lane of a round touched another 128-byte line and the rounds cost 0.45 of 2.37 ms, tools/layer_bench).  The 16 tiles
 //     of a ds_read_b64 service group lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 pixels).
 //   * V is never stored: per 8-channel unit a lane reads, for each of the 6 patch columns, its 2 contributing rows (ds_read_b64:
-//     two channels), forms t = x +- y, and folds it into the six V[b] (even/odd split of the +-p columns) — under the previous
-//     unit's 48 MFMAs, one VALU instruction per MFMA.
+//     two channels) and forms t = x +- y; the six V[b] follow from the six t (even/odd split of the +-p columns) — 40 VALU
+//     instructions under the previous unit's 48 MFMAs.
 //   * B (U quads: the four channel groups of one (b, k-step)) straight from L2 into a ring of six quads, refilled right after use.
 //   * epilogue: column transform in registers (6 -> 4); the row transform (4 -> 2) needs all four waves' rows: wave w takes the
 //     tile quarter r = w (tiles 4g + w, all 64 channels), the other three rows come through LDS (48 KiB, one pass); bias, ReLU,
@@ -172,38 +172,43 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     f32x4 acc[6][4];   // [position b][channel group cg]; first written by the zero-C MFMAs of unit 0
     float vcur[6][2];
     f32x2 rawx, rawy;
-    // the next unit's V, column by column: V0 = P0, V1/V2 = E12 +- O12, V3/V4 = E34 +- O34, V5 = P5 (the +-p rows of B^T share
-    // their even and odd parts); a column's t = x + sgn*y is folded into these six as soon as it is formed
-    float P0[2], E12[2], O12[2], E34[2], O34[2], P5[2];
+    // the next unit's V: the six column sums t[c] = x + sgn*y first, then V0 = t4 + (81/64) t0 - (45/16) t2, V1/V2 = E12 +- O12,
+    // V3/V4 = E34 +- O34, V5 = t5 + (81/64) t1 - (45/16) t3 (the +-p rows of B4^T share their even and odd parts): 12 + 28 VALU per unit
+    float t[6][2], vnxt[6][2];
     auto read_col = [&](int bufhalf, int c) {              // bufhalf = 2 * buf * BUF + s2 (f32x2 units)
         rawx = lds2[bufhalf + xbase + col_off(c)];
         rawy = lds2[bufhalf + ybase + col_off(c)];
     };
     auto fold_col = [&](int c) {
 #pragma unroll
+        for (int e = 0; e < 2; ++e) t[c][e] = __builtin_fmaf(sgn, rawy[e], rawx[e]);
+    };
+    auto make_v = [&](float (&v)[6][2], int part) {       // part 0: b = 0, 1, 2; part 1: b = 3, 4, 5
+#pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float t = __builtin_fmaf(sgn, rawy[e], rawx[e]);
-            if (c == 0) P0[e] = 1.265625f * t;
-            if (c == 1) { O12[e] = -1.6875f * t; O34[e] = -0.84375f * t; P5[e] = 1.265625f * t; }
-            if (c == 2) { P0[e] = __builtin_fmaf(-2.8125f, t, P0[e]); E12[e] = -2.25f * t; E34[e] = -0.5625f * t; }
-            if (c == 3) { O12[e] = __builtin_fmaf(0.75f, t, O12[e]); O34[e] = __builtin_fmaf(1.5f, t, O34[e]); P5[e] = __builtin_fmaf(-2.8125f, t, P5[e]); }
-            if (c == 4) { P0[e] += t; E12[e] += t; E34[e] += t; }
-            if (c == 5) P5[e] += t;
+            if (part == 0) {
+                v[0][e] = __builtin_fmaf(1.265625f, t[0][e], __builtin_fmaf(-2.8125f, t[2][e], t[4][e]));
+                const float ev = __builtin_fmaf(-2.25f, t[2][e], t[4][e]);
+                const float od = __builtin_fmaf(-1.6875f, t[1][e], 0.75f * t[3][e]);
+                v[1][e] = ev + od;
+                v[2][e] = ev - od;
+            } else {
+                const float ev = __builtin_fmaf(-0.5625f, t[2][e], t[4][e]);
+                const float od = __builtin_fmaf(-0.84375f, t[1][e], 1.5f * t[3][e]);
+                v[3][e] = ev + od;
+                v[4][e] = ev - od;
+                v[5][e] = __builtin_fmaf(1.265625f, t[1][e], __builtin_fmaf(-2.8125f, t[3][e], t[5][e]));
+            }
         }
     };
     auto finish_v = [&]() {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            vcur[0][e] = P0[e];
-            vcur[1][e] = E12[e] + O12[e];
-            vcur[2][e] = E12[e] - O12[e];
-            vcur[3][e] = E34[e] + O34[e];
-            vcur[4][e] = E34[e] - O34[e];
-            vcur[5][e] = P5[e];
-        }
+        for (int b = 0; b < 6; ++b) { vcur[b][0] = vnxt[b][0]; vcur[b][1] = vnxt[b][1]; }
     };
 #pragma unroll
     for (int c = 0; c < 6; ++c) { read_col(0, c); fold_col(c); }
+    make_v(vnxt, 0);
+    make_v(vnxt, 1);
     finish_v();
 
     // Chunk ck in LDS buffer PAR: two units (s2 = 0, 1: the two channel pairs of every quad).  Unit = 12 groups of four MFMAs
@@ -225,6 +230,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 if (build) {   // column grp is read here and folded one group later, under four MFMAs
                     if (grp >= 1 && grp <= 6) fold_col(grp - 1);
                     if (grp < 6) read_col(nhalf, grp);
+                    if (grp == 8) make_v(vnxt, 0);
+                    if (grp == 10) make_v(vnxt, 1);
                 }
                 if (DMA && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(PAR, ck + 2, grp - 6);
 #pragma unroll
