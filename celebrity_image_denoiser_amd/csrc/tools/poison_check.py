@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/../../..")
 import celebrity_image_denoiser_amd as cid
 from celebrity_image_denoiser_amd import synth
 N, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (192, 128, 128)))
-algo = sys.argv[4] if len(sys.argv) > 4 else "winograd64"
+algo = sys.argv[4] if len(sys.argv) > 4 else "winograd42"
 dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
 m = cid.load(synth.make_state_dict("hot"), device="cuda:0", strict=True)
 m.conv_algo = algo

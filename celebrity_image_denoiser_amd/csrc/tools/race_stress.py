@@ -1,4 +1,4 @@
-"""Ad-hoc: many large random batches through the Winograd path (fused and unfused last layer) and the direct path; a
+"""Ad-hoc: many large random batches through both Winograd paths (fused and unfused last layer) and the direct path; a
 synchronisation race (LDS-DMA waits, barriers, LDS reuse in the epilogues) would show up as a bit difference between two runs of
 one configuration, or as a difference beyond the fp32 tolerance between configurations."""
 import sys, os, numpy as np, torch
@@ -11,11 +11,13 @@ bad = 0
 for it in range(40):
     n, hw = (192, 128) if it % 2 == 0 else (96, int(torch.randint(33, 200, (1,)).item()))
     x = (torch.rand((n, 3, hw, hw + (it % 5) * 3), device="cuda:0", generator=g) * 2 - 1).contiguous()
-    m.conv_algo, m.tail_algo = "winograd64", "fused"; a = m(x).clone(); b = m(x).clone()
+    m.conv_algo, m.tail_algo = "winograd42", "fused"; a = m(x).clone(); b = m(x).clone()
     m.tail_algo = "bands"; c = m(x).clone(); c2 = m(x).clone()
+    m.conv_algo, m.tail_algo = "winograd64", "fused"; e = m(x).clone(); e2 = m(x).clone()
     m.conv_algo, m.tail_algo = "direct", "tiles"; d = m(x).clone()
     torch.cuda.synchronize()
-    if not (torch.equal(a, b) and torch.equal(c, c2) and float((a - c).abs().max()) <= 1e-5 and float((a - d).abs().max()) <= 1e-5):
-        bad += 1; print("MISMATCH at iteration", it, tuple(x.shape), float((a - b).abs().max()), float((a - c).abs().max()), float((a - d).abs().max()))
+    if not (torch.equal(a, b) and torch.equal(c, c2) and torch.equal(e, e2) and float((a - c).abs().max()) <= 1e-5
+            and float((a - d).abs().max()) <= 1e-5 and float((a - e).abs().max()) <= 1e-5):
+        bad += 1; print("MISMATCH at iteration", it, tuple(x.shape), float((a - b).abs().max()), float((a - c).abs().max()), float((a - d).abs().max()), float((a - e).abs().max()))
 print("iterations with a mismatch:", bad)
 sys.exit(1 if bad else 0)
