@@ -129,13 +129,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             voff_tab[m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
         }
     }
-    const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
+    // LDS-DMA through the compiler's builtin (buffer_load_dwordx4 ... offen lds; M0 = the wave-uniform LDS address): hipcc then counts
+    // the rounds in its vmcnt bookkeeping, so its waits for the B quads are exact (with inline asm they were one load early per round in
+    // flight: +0.3 % same-box)
     auto dma_round = [&](int buf, int ck, int m) {   // round m of this wave: 64 quads of chunk ck -> LDS buffer `buf`
         if (wave + 4 * m < NROUND) {                   // wave-uniform
-            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
             const int soff = ck * (WK * 4);
             const unsigned vo = voff_tab[m * 64];
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vo), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)&lds[buf * BUF + (wave + 4 * m) * 64], 16, vo, soff, 0, 0);
         }
     };
     auto dma_chunk = [&](int buf, int ck) {
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) bq[q] = b_load(0, q);
     dma_chunk(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to hipcc's own wait counting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk 0 has landed (this wave); past the barrier: every wave's part
     __syncthreads();
 
     f32x4 acc[6][4];   // [position b][channel group cg]; first written by the zero-C MFMAs of unit 0
