@@ -531,14 +531,14 @@ def test_out_argument_and_mixed_formats(models):
 
 
 def test_seeded_shape_sweep_against_cpu_oracle(models, weight_sets):
-    """Twelve seeded (N, H, W) draws with H, W in [4, 150] — tile boundaries of every kernel (32/64-pixel tile columns,
+    """Fourteen seeded (N, H, W) draws with H, W in [4, 150] — tile boundaries of every kernel (32/64-pixel tile columns,
     2/4/8-row tiles, the W <= 32 variants), odd sizes that exercise the crop path, single rows of tiles — against the
     ATen oracle at the stated tolerance."""
     from oracle import torch_oracle
 
     rng = np.random.default_rng(20240607)
     shapes = [(int(rng.integers(1, 4)), int(rng.integers(4, 151)), int(rng.integers(4, 151))) for _ in range(10)]
-    shapes += [(1, 33, 65), (2, 130, 31)]
+    shapes += [(1, 33, 65), (2, 130, 31), (1, 20, 36), (2, 68, 132)]   # the last two: every level a partial 32x4 / 16x8 Winograd F(4x2) workgroup tile
     for k, (n, h, w) in enumerate(shapes):
         wset = "hot" if k % 2 else "default"
         x, _, _ = synth.make_batch(n, h, w, first_index=2000 + 10 * k)
