@@ -125,6 +125,13 @@ def test_stage_views_and_fused_launch_accounting():
     assert tot[_lib.CID_TAIL_BANDS][1] - tot[_lib.CID_TAIL_FUSED][1] == 4.0 * px * 2 * (64 - 27)   # the 64-channel tensor never exists
     assert L.cid_set_tail_algo(h, 7) == 1
     assert L.cid_set_conv_algo(h, 1) == 1 and b"unknown algorithm" in L.cid_last_error(h)   # round 1's first Winograd kernel is gone
+    import ctypes as _ct
+    algo = _ct.c_int(-1)
+    assert L.cid_get_conv_algo(h, _ct.byref(algo)) == 0 and algo.value == _lib.CID_ALGO_WINOGRAD42   # the default: Winograd F(4x2,3x3)
+    for a in (_lib.CID_ALGO_DIRECT, _lib.CID_ALGO_WINOGRAD64, _lib.CID_ALGO_WINOGRAD42):
+        assert L.cid_set_conv_algo(h, a) == 0 and L.cid_get_conv_algo(h, _ct.byref(algo)) == 0 and algo.value == a
+        assert L.cid_launch_kernel(h, 5).decode().startswith({_lib.CID_ALGO_DIRECT: "k_gemm_conv<256, 256", _lib.CID_ALGO_WINOGRAD64: "k_wino64_conv<256, 256",
+                                                              _lib.CID_ALGO_WINOGRAD42: "k_wino42_conv<256, 256"}[a])
     L.cid_destroy(h)
 
 
