@@ -54,6 +54,7 @@ SYMBOLS = {
     "cid_launch_work_ex": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "cid_stage_view": (_c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int),
                                   _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "cid_comm_available": (_c.c_int, []),
     "cid_comm_unique_id": (_c.c_int, [_c.c_void_p]),
     "cid_comm_init_rank": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_void_p, _c.c_int]),
     "cid_comm_destroy": (_c.c_int, [_c.c_void_p]),

@@ -36,6 +36,19 @@ def extract_state_dict(ckpt, key_candidates: Sequence[str] = ("generator", "stat
     return out
 
 
+def _numpy_scalar_globals():
+    """What a pickled numpy scalar refers to (numpy 2 and numpy 1 spellings): the reconstruct function, `numpy.dtype` and the
+    concrete dtype classes of the numeric kinds a metric can have.  Data constructors only — none of them runs file-supplied code."""
+    import numpy as np
+
+    try:
+        from numpy._core.multiarray import scalar
+    except ImportError:   # numpy < 2
+        from numpy.core.multiarray import scalar
+    kinds = ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool")
+    return [scalar, np.dtype] + sorted({type(np.dtype(k)) for k in kinds}, key=lambda t: t.__name__)
+
+
 def _read_checkpoint_file(path: str) -> Mapping:
     """Checkpoint file -> flat state_dict of CPU tensors.
 
@@ -53,14 +66,18 @@ def _read_checkpoint_file(path: str) -> Mapping:
         return {k: torch.from_numpy(v) for k, v in read_state_dict(path).items()}
     except (ValueError, zipfile.BadZipFile) as e:
         logger.info("%s is not a zip checkpoint (%s): reading the legacy format with torch.load(weights_only=True)", path, e)
-        return extract_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return extract_state_dict(torch.load(path, map_location="cpu", weights_only=True))
 
 
 def load_state_safely(model: torch.nn.Module, checkpoint_path: str,
                       key_candidates: Sequence[str] = ("generator", "state_dict", "G")) -> None:
     """torch.load -> extract_state_dict -> load_state_dict(strict=False) -> eval()  (app.py:257-274).
-    weights_only=True: the trainer's checkpoint (training.py:359-376) holds only tensors and plain containers."""
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    weights_only=True with the numpy-scalar globals allow-listed: besides tensors and plain containers the trainer's
+    checkpoint holds np.float64 values (`best_psnr`, `metric_history` = np.mean(...) results, training.py:368-369,449-465),
+    which is why the reference itself reads it with weights_only=False (app.py:258); nothing else is let through."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     model.load_state_dict(extract_state_dict(ckpt, key_candidates), strict=False)
     model.eval()
     logger.info("Loaded PyTorch weights from %s", checkpoint_path)

@@ -7,6 +7,12 @@ The reference's trainer writes `torch.save({"generator": state_dict, "discrimina
 storage bytes).  This reader unpickles with a closed allow-list of globals — nothing from the file can run code —
 and returns tensors as numpy arrays.  Non-tensor entries (epoch, metric history, optimizer hyper-parameters) come
 back as plain Python objects.
+
+The trainer's `best_psnr` and `metric_history` values are `np.mean(...)` results (training.py:272-273, 449-465), i.e.
+numpy.float64 scalars, which pickle as `numpy._core.multiarray.scalar(numpy.dtype("f8"), <8 bytes>)` (numpy >= 2;
+`numpy.core.multiarray.scalar` before).  Those two globals are answered by closed handlers here — a fixed table of
+numeric dtype codes, the bytes decoded into a Python int/float/bool — so real `denoise_epoch_*.pth` files load and
+still nothing from the file is called.
 """
 from __future__ import annotations
 
@@ -52,6 +58,42 @@ def _rebuild_parameter(data, requires_grad=False, backward_hooks=None):
     return data
 
 
+# numpy scalars inside a checkpoint (see the module docstring): dtype code -> numpy type, nothing else is accepted
+_SCALAR_CODES = {
+    "f8": np.float64, "f4": np.float32, "f2": np.float16, "i8": np.int64, "i4": np.int32, "i2": np.int16, "i1": np.int8,
+    "u8": np.uint64, "u4": np.uint32, "u2": np.uint16, "u1": np.uint8, "b1": np.bool_,
+}
+
+
+class _ScalarDtype:
+    """Stand-in for `numpy.dtype(code, align, copy)` + its pickled state `(version, byteorder, ...)`."""
+
+    def __init__(self, code, *_ignored):
+        if not isinstance(code, str) or code not in _SCALAR_CODES:
+            raise pickle.UnpicklingError(f"checkpoint holds a numpy scalar of dtype {code!r}, which this reader does not allow")
+        self.dtype = np.dtype(_SCALAR_CODES[code])
+
+    def __setstate__(self, state):
+        order = state[1] if isinstance(state, tuple) and len(state) > 1 else "="
+        if order not in ("<", ">", "=", "|"):
+            raise pickle.UnpicklingError("numpy dtype with an unknown byte order in checkpoint")
+        if order in ("<", ">"):
+            self.dtype = self.dtype.newbyteorder(order)
+
+
+def _latin1_bytes(text, encoding="latin1"):
+    """`_codecs.encode(str, "latin1")`: how pickle protocol 2 (torch.save's default) spells a bytes object."""
+    if not isinstance(text, str) or encoding != "latin1" or len(text) > 16:
+        raise pickle.UnpicklingError("unexpected _codecs.encode call in checkpoint")
+    return text.encode("latin1")
+
+
+def _numpy_scalar(dtype, raw):
+    if not isinstance(dtype, _ScalarDtype) or not isinstance(raw, (bytes, bytearray)) or len(raw) != dtype.dtype.itemsize:
+        raise pickle.UnpicklingError("malformed numpy scalar in checkpoint")
+    return np.frombuffer(bytes(raw), dtype=dtype.dtype)[0].item()   # a plain Python number
+
+
 class _Unpickler(pickle.Unpickler):
     def __init__(self, f, zf, prefix):
         super().__init__(f)
@@ -66,6 +108,12 @@ class _Unpickler(pickle.Unpickler):
             return _rebuild_parameter
         if module == "torch" and name in _DTYPES:
             return _StorageType(name)
+        if module in ("numpy", "numpy.core", "numpy._core") and name == "dtype":
+            return _ScalarDtype
+        if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name == "scalar":
+            return _numpy_scalar
+        if module == "_codecs" and name == "encode":
+            return _latin1_bytes
         if module == "builtins" and name in ("dict", "list", "tuple", "set", "int", "float", "str", "bool"):
             return __import__("builtins").__dict__[name]
         raise pickle.UnpicklingError(f"checkpoint references {module}.{name}, which this reader does not allow")

@@ -923,6 +923,7 @@ int rccl_fail(cid_handle_t h, const char* what, int rc) {
 }  // namespace
 extern "C" {
 
+int cid_comm_available(void) { return rccl().ok ? 1 : 0; }
 int cid_comm_unique_id(void* id128) {
     if (!id128) return CID_ERR_INVALID;
     if (!rccl().ok) return CID_ERR_STATE;

@@ -3,7 +3,7 @@
 Every image is independent in the forward (no batch-norm or cross-sample op; reference
 backend/app.py:80-103), so the batch dimension is split contiguously over the ranks and the
 forward needs no communication.  The only collective is one broadcast of the packed weights blob
-(cid_packed_weights_bytes(), ~26 MB: every kernel layout plus a reference-layout copy) from the rank that loaded the checkpoint:
+(cid_packed_weights_bytes(): every kernel layout plus a reference-layout copy, tens of MB) from the rank that loaded the checkpoint:
 `cid_broadcast_weights` = one `ncclBroadcast` (RCCL over xGMI) issued by libcid.so; torch.distributed carries only the 128-byte communicator id.  The reference has no
 distributed code; this is the build's own data-parallel driver.
 """
@@ -28,28 +28,85 @@ def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return begin, begin + q + (1 if rank < r else 0)
 
 
+def _rccl_available() -> bool:
+    """Can libcid.so reach an RCCL in this process (include/cid.h: cid_comm_available)?  Purely local, never raises."""
+    try:
+        return bool(_lib.lib().cid_comm_available())
+    except Exception:   # noqa: BLE001 - a library that cannot even be loaded has no RCCL transport either
+        return False
+
+
+def _agree(ok: bool, device: torch.device, group: Optional[dist.ProcessGroup]) -> bool:
+    """True iff EVERY rank of the group says ok — one MIN all-reduce that every rank reaches whatever happened before it."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 class WeightsComm:
     """An RCCL communicator over the ranks of a torch.distributed group, created through the C ABI
     (cid_comm_unique_id / cid_comm_init_rank, include/cid.h) so that the job's one collective — the broadcast of the
     packed weights — is an `ncclBroadcast` issued by libcid.so itself.  torch.distributed is only the control channel
-    that carries the 128-byte unique id from rank `src` to the others."""
+    that carries the 128-byte unique id from group rank 0 to the others.
 
-    def __init__(self, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+    Build one with `WeightsComm.negotiate`: every step in it that can fail on one rank only is followed by an agreement
+    all-reduce, and every rank issues the same sequence of torch.distributed collectives on every path — a rank that
+    cannot set the communicator up makes ALL ranks fall back together instead of leaving its peers inside a collective
+    it never joins (VERDICT r2 / ADVICE r2: the id exchange used to be skipped by a failing rank 0)."""
+
+    def __init__(self, comm, lib):
+        self._comm, self._L = comm, lib
+
+    # the two C-ABI steps, as methods so that the CPU test-suite can stand in for them
+    @staticmethod
+    def _make_unique_id() -> bytes:
         import ctypes
 
-        self._L = _lib.lib()
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        ident = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            buf = (ctypes.c_char * 128)()
-            _lib.check(None, self._L.cid_comm_unique_id(buf))
-            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        box = [ident.tolist()]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        raw = bytes(box[0])
-        self._comm = ctypes.c_void_p()
+        buf = (ctypes.c_char * 128)()
+        _lib.check(None, _lib.lib().cid_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @staticmethod
+    def _init_rank(device: torch.device, world: int, ident: bytes, rank: int):
+        import ctypes
+
+        comm = ctypes.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(None, self._L.cid_comm_init_rank(ctypes.byref(self._comm), self.world, raw, self.rank))
+            _lib.check(None, _lib.lib().cid_comm_init_rank(ctypes.byref(comm), world, ident, rank))
+        return comm
+
+    @classmethod
+    def negotiate(cls, device: torch.device, group: Optional[dist.ProcessGroup] = None) -> Optional["WeightsComm"]:
+        """-> a communicator on every rank, or None on every rank (then the caller uses torch.distributed.broadcast).
+        Collectives issued, identically on all ranks: all-reduce (RCCL reachable everywhere?) -> [stop if not] ->
+        broadcast_object_list (the id, or None if group rank 0 could not make one) -> [stop if None] -> communicator
+        set-up -> all-reduce (set up everywhere?)."""
+        import logging
+
+        log = logging.getLogger("cid")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if not _agree(_rccl_available(), device, group):
+            log.warning("RCCL is not reachable from libcid.so on every rank: broadcasting the blob with torch.distributed")
+            return None
+        box = [None]
+        if rank == 0:
+            try:
+                box = [list(cls._make_unique_id())]
+            except Exception as e:   # noqa: BLE001 - still take part in the exchange below: the others are waiting in it
+                log.warning("cid_comm_unique_id failed (%s)", e)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None:
+            return None              # every rank sees the same marker: no further collective needed to agree
+        comm = None
+        try:
+            comm = cls._init_rank(device, world, bytes(box[0]), rank)
+        except Exception as e:   # noqa: BLE001
+            log.warning("cid_comm_init_rank failed on rank %d (%s)", rank, e)
+        if not _agree(comm is not None, device, group):
+            if comm is not None:
+                cls(comm, _lib.lib()).close()
+            return None
+        return cls(comm, _lib.lib())
 
     def close(self) -> None:
         if self._comm:
@@ -64,56 +121,48 @@ class WeightsComm:
 
 
 def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
-    """Give every rank the weights of rank `src` with ONE broadcast of the packed blob.
+    """Give every rank the weights of rank `src` with ONE broadcast of the packed blob.  `src` is a GLOBAL rank, as in
+    torch.distributed.broadcast; inside a sub-group it is translated to the group rank RCCL counts in.
 
     GPU ranks: `cid_broadcast_weights` — one in-place `ncclBroadcast` (RCCL over xGMI) of the device blob, issued from
     the C ABI on the current stream; receivers attach it and refresh their nn.Parameters from it.  CPU ranks (gloo,
     the CPU test-suite): the same bytes travel as a host tensor through torch.distributed."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)                                              # rank inside the group
+    root = dist.get_group_rank(group, src) if group is not None else src     # src inside the group (what RCCL calls root)
+    is_src = rank == root
     dev = next(model.parameters()).device
     on_gpu = dev.type == "cuda"
     L = _lib.lib()
     nbytes = L.cid_packed_weights_bytes()
     if not on_gpu:
-        blob = model.pack_weights_host() if rank == src else torch.empty(nbytes, dtype=torch.uint8)
+        blob = model.pack_weights_host() if is_src else torch.empty(nbytes, dtype=torch.uint8)
         dist.broadcast(blob, src=src, group=group)
-        if rank != src:
+        if not is_src:
             model.adopt_packed_weights(blob, update_parameters=True)
         return
     # Transport 1: ncclBroadcast issued by libcid.so on its own communicator (cid_broadcast_weights).  Transport 2, only if
-    # the first cannot be set up on this host (no RCCL found at run time, communicator creation refused): the same bytes as
+    # the first cannot be set up on some rank (no RCCL found at run time, communicator creation refused): the same bytes as
     # ONE torch.distributed.broadcast on the process group's backend (nccl = the same RCCL over xGMI).  Either way it is one
-    # collective of the packed blob; every rank takes the same branch (the choice is agreed on with an all-reduce).
-    import logging
-
-    comm, ok = None, 1
-    try:
-        comm = WeightsComm(dev, group)
-    except Exception as e:   # noqa: BLE001 - any set-up failure selects transport 2 on ALL ranks
-        logging.getLogger("cid").warning("cid_comm_* unavailable (%s): broadcasting the blob with torch.distributed", e)
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
-        if comm is not None:
-            comm.close()
-        blob = model.pack_weights() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # collective of the packed blob, and every rank takes the same branch (WeightsComm.negotiate).
+    comm = WeightsComm.negotiate(dev, group)
+    if comm is None:
+        blob = model.pack_weights() if is_src else torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dist.broadcast(blob, src=src, group=group)
-        if rank != src:
+        if not is_src:
             model.adopt_packed_weights(blob, update_parameters=True)
         return
     try:
-        if rank == src:
+        if is_src:
             blob = model.pack_weights()
         else:
             blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(model._cid, L.cid_attach_weights(model._cid, blob.data_ptr()))
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(model._cid, L.cid_broadcast_weights(model._cid, comm._comm, src, rank, stream))
-        if rank != src:
+            _lib.check(model._cid, L.cid_broadcast_weights(model._cid, comm._comm, root, rank, stream))
+        if not is_src:
             model.adopt_packed_weights(blob, update_parameters=True, host_is_current=True)
         torch.cuda.current_stream(dev).synchronize()
     finally:

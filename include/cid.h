@@ -218,6 +218,7 @@ int cid_stage_view(const char* stage, int N, int H, int W, size_t* offset_bytes,
  *            refreshed their host copy (the call synchronises `stream` there), so cid_get_weight returns the new tensors.
  * RCCL is resolved at run time from the process (dlopen of librccl.so.1): CID_ERR_STATE if it is not available.
  */
+int cid_comm_available(void);   /* 1 if RCCL could be resolved in this process (the three calls below can work), else 0; no side effect */
 int cid_comm_unique_id(void* id128);
 int cid_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
 int cid_comm_destroy(void* comm);

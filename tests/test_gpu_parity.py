@@ -617,13 +617,16 @@ def test_rccl_broadcast_through_the_c_abi(weight_sets):
 
     if not dist.is_initialized():
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    L_available = lambda: _lib.lib().cid_comm_available() == 1   # noqa: E731
     try:
         src = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
         x, _, _ = synth.make_batch(2, 32, 32, first_index=1400)
         want = _run(src, x)
         cdist.broadcast_weights(src, src=0)                 # comm init + ncclBroadcast (root side) + comm destroy
         assert np.array_equal(_run(src, x), want)
-        comm = cdist.WeightsComm(torch.device("cuda:0"))
+        assert L_available()
+        comm = cdist.WeightsComm.negotiate(torch.device("cuda:0"))
+        assert comm is not None
         dst = cid.load(None, device="cuda:0")               # random init, like a rank that read no checkpoint
         blob = src.pack_weights().clone()
         L = _lib.lib()

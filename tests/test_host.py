@@ -160,6 +160,56 @@ def test_torch_free_checkpoint_reader(tmp_path):
     assert list(got2.keys()) == list(ref.keys()) and all(np.array_equal(got2[k].numpy(), ref[k]) for k in ref)
 
 
+def test_trainer_checkpoint_with_numpy_scalars_loads(tmp_path):
+    """the trainer's own checkpoints carry numpy.float64 scalars — `best_psnr` and every `metric_history`
+    entry are np.mean(...) results (training.py:272-273,368-369,449-465) — beside real Adam / StepLR state_dicts
+    (training.py:239-242,362-366).  Every loader that takes a path must open such a file, and still refuse other globals."""
+    import pickle
+    import zipfile
+
+    from celebrity_image_denoiser_amd import api, ckpt
+
+    ref = synth.make_state_dict("default")
+    sd = {k: torch.from_numpy(v) for k, v in ref.items()}
+    disc = torch.nn.Conv2d(3, 4, 3)
+    opt = torch.optim.Adam(disc.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=30, gamma=0.1)
+    disc(torch.zeros(1, 3, 8, 8)).sum().backward()
+    opt.step()
+    sched.step()
+    state = {"generator": sd, "discriminator": disc.state_dict(), "g_optimizer": opt.state_dict(), "d_optimizer": opt.state_dict(),
+             "scheduler_g": sched.state_dict(), "scheduler_d": sched.state_dict(), "epoch": 499,
+             "best_psnr": np.mean([30.5, 31.25]),
+             "metric_history": {"psnr": [np.mean([1.0, 2.0]), np.float32(3.0)], "ssim": [np.float64(0.9)], "g_loss": [0.5], "count": [np.int64(3)]}}
+    assert type(state["best_psnr"]).__module__ == "numpy"
+    path = os.path.join(tmp_path, "denoise_epoch_499.pth")
+    torch.save(state, path)
+    whole = ckpt.read_checkpoint(path)
+    assert whole["best_psnr"] == 30.875 and type(whole["best_psnr"]) is float
+    assert whole["metric_history"] == {"psnr": [1.5, 3.0], "ssim": [0.9], "g_loss": [0.5], "count": [3]}
+    assert whole["g_optimizer"]["param_groups"][0]["betas"] == (0.9, 0.999) and whole["scheduler_g"]["step_size"] == 30
+    got = api._read_checkpoint_file(path)
+    assert list(got.keys()) == list(ref.keys()) and all(np.array_equal(got[k].numpy(), ref[k]) for k in ref)
+    m = cid.DenoiseGenerator()
+    api.load_state_safely(m, path)               # the reference loader's name and semantics (app.py:257-274)
+    assert not m.training and all(np.array_equal(m.state_dict()[k].numpy(), ref[k]) for k in ref)
+    legacy = os.path.join(tmp_path, "legacy_np.pth")
+    torch.save(state, legacy, _use_new_zipfile_serialization=False)
+    got2 = api._read_checkpoint_file(legacy)
+    assert all(np.array_equal(got2[k].numpy(), ref[k]) for k in ref)
+    # the handlers are closed: an object dtype, a structured dtype or a non-latin1 encode is refused
+    for bad in (ckpt._ScalarDtype, ckpt._latin1_bytes):
+        with pytest.raises(pickle.UnpicklingError):
+            bad("O8") if bad is ckpt._ScalarDtype else bad("x", "utf-16")
+    with pytest.raises(pickle.UnpicklingError):
+        ckpt._numpy_scalar(ckpt._ScalarDtype("f8"), b"\x00" * 4)
+    evil = os.path.join(tmp_path, "evil_np.pth")
+    with zipfile.ZipFile(evil, "w") as zf:
+        zf.writestr("archive/data.pkl", pickle.dumps({"generator": {}, "best_psnr": np.array([1.0])}, protocol=2))
+    with pytest.raises(pickle.UnpicklingError):   # numpy arrays (numpy._core.multiarray._reconstruct) are not scalars: still refused
+        ckpt.read_checkpoint(evil)
+
+
 def test_checkpoint_reader_bounds_checks_tensor_views(tmp_path):
     """size/stride/offset come from the file; a view that reaches past its storage must be refused, not read
     (as_strided without a bounds check)."""
