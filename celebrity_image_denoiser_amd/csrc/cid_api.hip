@@ -161,7 +161,7 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
 
 // Winograd F(4x2,3x3) filter transform U = G2 g G4^T — rows by the F(2,3) matrix of pack_winograd_u, columns by F(4,3) at the
 // points 0, 3/4, -3/4, 3/2, -3/2, inf (24 values per (co, ci)) —, in double, rounded once to fp32, laid out for k_wino42_conv:
-//   [nb = co/64][unit = ci/8][a][q = 6*e2 + b][lane = 16*g + j][cg],   ci = 16*(unit/2) + 4*g + 2*(unit%2) + e2,  co = 64*nb + 16*cg + j
+//   [nb = co/64][unit][a][q = 6*e2 + b][lane = 16*g + j][cg],   ci = 16*(unit/2) + 4*g + 2*((unit%2) ^ (g&1)) + e2,  co = 64*nb + 16*cg + j
 // (one 16-byte quad per lane = the four channel groups of position (a, b) at k-step e2: one V value, four MFMAs)
 void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
     static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -179,7 +179,9 @@ void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
             for (int a = 0; a < 4; ++a)
                 for (int q = 0; q < 3; ++q) tmp[a][q] = G2[a][0] * g[0 * 3 + q] + G2[a][1] * g[1 * 3 + q] + G2[a][2] * g[2 * 3 + q];
             const int nb = co >> 6, cg = (co >> 4) & 3, j = co & 15;
-            const int ck = ci >> 4, gg = (ci >> 2) & 3, s2 = (ci >> 1) & 1, e2 = ci & 1;
+            // lane group gg reads the 8-byte half (ci >> 1) & 1 of its LDS quad for unit s2 = half ^ (gg & 1): odd channel groups take
+            // the halves in the other order, which makes the kernel's ds_read_b64 conflict-free (wino42_kernels.h, xbase / ybase)
+            const int ck = ci >> 4, gg = (ci >> 2) & 3, s2 = ((ci >> 1) & 1) ^ (gg & 1), e2 = ci & 1;
             const int unit = ck * 2 + s2;
             for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 6; ++b) {
@@ -224,8 +226,8 @@ bool make_dims(int N, int H, int W, Dims& d) {
 //   * the kernels address ONE image's activations through a raw buffer descriptor with 32-bit byte offsets, and a lane
 //     that must deliver zeros (convolution padding, ragged tiles) carries the offset 0x7ffffff0, which has to lie beyond
 //     the descriptor's range.  The widest per-image tensor is cat1 = [4*(H/4), 4*(W/4), 128] fp32 (512 bytes per pixel);
-//   * tile decode divides by multiply-high with 32-bit reciprocals: exact while (tiles) x (tiles per image) < 2^32; the
-//     finest tiling of any launch is k_wino64_conv's at full resolution, 2 rows x 64 columns per tile.
+//   * tile decode divides by multiply-high with 32-bit reciprocals: exact while (tiles of the launch) x (tiles per image) < 2^32,
+//     i.e. N x t^2 < 2^32 with t = the most tiles (or blocks) per image of any launch: every tiling in use is listed below.
 // Larger inputs are an error (CID_ERR_SHAPE), never wrong results: split the batch, or the image into stripes
 // (api.serve_u8 does).
 constexpr unsigned long long kZeroSentinel = 0x7ffffff0ull;
@@ -233,7 +235,14 @@ const char* shape_error(int N, int H, int W, Dims& d) {
     if (!make_dims(N, H, W, d)) return "N >= 1 and H, W >= 4 required (output size is too small)";
     if ((unsigned long long)H * W * 512ull >= kZeroSentinel)
         return "image too large for one call: H*W must stay below 4,194,303 pixels (32-bit per-image addressing); split it into stripes";
-    const unsigned long long t0 = (unsigned long long)cdiv_ull(W, 64) * cdiv_ull(H, 2) + (unsigned long long)cdiv_ull(W, TILE_W) * cdiv_ull(H, TILE_H);
+    unsigned long long t0 = 0;
+    const unsigned long long per_image[] = {
+        cdiv_ull(W, 32) * cdiv_ull(H, 4), cdiv_ull(W, 16) * cdiv_ull(H, 8),          // k_wino42_conv: 8 x 2 / 4 x 4 tiles of 4x2 pixels
+        cdiv_ull(W, 64) * cdiv_ull(H, 2), cdiv_ull(W, 32) * cdiv_ull(H, 4),          // k_wino64_conv: 32 x 1 / 16 x 2 tiles of 2x2 pixels
+        cdiv_ull(W, TILE_W) * cdiv_ull(H, TILE_H),                                   // head, tail, k_gemm_conv, the fp16 kernels
+        cdiv_ull((unsigned long long)H * W, THREADS),                                // k_conv_tail_z: one thread per pixel
+    };
+    for (unsigned long long t : per_image) t0 = t > t0 ? t : t0;
     if ((unsigned long long)N * t0 * t0 >= (1ull << 32)) return "batch x image too large for one call (split the batch)";
     return nullptr;
 }

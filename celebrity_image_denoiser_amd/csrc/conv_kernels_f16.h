@@ -291,15 +291,14 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
     const int wbase = nb * NSUB * (BSUB * 16);
-    const unsigned lds_b = (unsigned)(uintptr_t)(&lds[HALO_SLOTS]);
     const unsigned vlane = lane * 16;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     auto dma_b = [&](int g) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const unsigned dst = lds_b + (unsigned)((((g & 1) * BSUB) + (wave_s + 4 * j) * 64) * 16);
             const int soff = wbase + g * (BSUB * 16) + (wave_s + 4 * j) * 1024;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(vlane), "s"(rsrc_w), "s"(dst), "s"(soff) : "memory");
+            // the compiler's builtin (not inline asm writing M0 behind its back): M0 and the vmcnt bookkeeping are hipcc's
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)&lds[HALO_SLOTS + ((g & 1) * BSUB) + (wave_s + 4 * j) * 64], 16, vlane, soff, 0, 0);
         }
     };
 #ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 stamps s_memtime at the phase boundaries into a.pool, results unchanged

@@ -22,7 +22,8 @@
 //     offset, the range check writes zeros).  Layout [row][x mod 4][x div 4] of pixels, pixel = 4 channel-group quads + 1 pad
 //     quad (as k_wino64_conv: four DMA lanes fetch one pixel's 64 contiguous bytes; with the channel groups in separate planes
 //     every lane of a round touched another 128-byte line and the rounds cost 0.45 of 2.37 ms, tools/layer_bench).  The 16 tiles
-//     of a ds_read_b64 service group lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 pixels).
+//     of a channel group lie in 16 different quads (mod 16) for every tile shape (row stride 68 / 36 / 26 pixels), and odd channel
+//     groups read the other 8-byte half of their quads, so the 32 lanes of a ds_read_b64 service group cover all 64 banks.
 //   * V is never stored: per 8-channel unit a lane reads, for each of the 6 patch columns, its 2 contributing rows (ds_read_b64:
 //     two channels) and forms t = x +- y; the six V[b] follow from the six t (even/odd split of the +-p columns) — 40 VALU
 //     instructions under the previous unit's 48 MFMAs.
@@ -158,8 +159,15 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     const int yrow = (wave == 0 || wave == 1) ? 2 : (wave == 2) ? 1 : 3;
     const float sgn = (wave == 1) ? 1.f : -1.f;
     const f32x2* lds2 = reinterpret_cast<const f32x2*>(lds);
-    // f32x2 index of (channel group g, patch rows xrow / yrow of tile row tr, x = 4 tc) in buffer 0, half 0
-    const int xbase = 2 * (WPS * ((2 * tr + xrow) * RS + tc) + g), ybase = 2 * (WPS * ((2 * tr + yrow) * RS + tc) + g);
+    // f32x2 index of (channel group g, patch rows xrow / yrow of tile row tr, x = 4 tc) in buffer 0, plus the 8-byte HALF of the
+    // quad this lane reads for the unit being built: half = s2 ^ (g & 1).  A ds_read_b64 is served in two groups of 32 lanes
+    // over 64 banks (MI355X_MICROARCH.md, LDS): with every lane on the SAME half of its 16-byte quad the 32 lanes of a group
+    // (two channel groups g x 16 tiles) touch only every other 8-byte slot — a 2-way conflict by construction, the 33-41 %
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 2.  With odd channel groups on the other half the 16 tiles of g even cover
+    // the 16 even slots (10 tc mod 32, + 16 tr for TC = 8, + 8 tr for TC = 4) and those of g odd the 16 odd ones: conflict-free.
+    // Unit (chunk, s2) therefore holds channels 4g + 2 (s2 ^ (g & 1)) + e2 of the chunk (pack_winograd42_u packs U to match);
+    // the half flips at every unit, one v_xor per base.
+    int xbase = 2 * (WPS * ((2 * tr + xrow) * RS + tc) + g) + (g & 1), ybase = 2 * (WPS * ((2 * tr + yrow) * RS + tc) + g) + (g & 1);
     auto col_off = [](int c) { return 2 * WPS * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, pixel tc + c / 4
 
     // ---- prologue ----
@@ -176,10 +184,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     // the next unit's V: the six column sums t[c] = x + sgn*y first, then V0 = t4 + (81/64) t0 - (45/16) t2, V1/V2 = E12 +- O12,
     // V3/V4 = E34 +- O34, V5 = t5 + (81/64) t1 - (45/16) t3 (the +-p rows of B4^T share their even and odd parts): 12 + 28 VALU per unit
     float t[6][2], vnxt[6][2];
-    auto read_col = [&](int bufhalf, int c) {              // bufhalf = 2 * buf * BUF + s2 (f32x2 units)
-        rawx = lds2[bufhalf + xbase + col_off(c)];
-        rawy = lds2[bufhalf + ybase + col_off(c)];
+    auto read_col = [&](int bufoff, int c) {               // bufoff = 2 * buf * BUF (f32x2 units); the half is in xbase / ybase
+        rawx = lds2[bufoff + xbase + col_off(c)];
+        rawy = lds2[bufoff + ybase + col_off(c)];
     };
+    auto flip_half = [&]() { xbase ^= 1; ybase ^= 1; };   // the next unit to be built reads the other half of every quad
     auto fold_col = [&](int c) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) t[c][e] = __builtin_fmaf(sgn, rawy[e], rawx[e]);
@@ -222,8 +231,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const bool build = ((k == 0) || MORE) && !(ABLATE & 4);
-            const int nhalf = (k == 0) ? 2 * PAR * BUF + 1 : 2 * (1 - PAR) * BUF;   // the next unit: this buffer's second half, or the other buffer
+            const int nhalf = (k == 0) ? 2 * PAR * BUF : 2 * (1 - PAR) * BUF;   // the next unit: this buffer's other half, or the other buffer
             const int gu = ck * 2 + k;
+            if (build) flip_half();
             if (FIRST && k == 0 && !(ABLATE & 1)) dma_chunk(1, 1);   // chunk 1 lands under unit 0
 #pragma unroll
             for (int grp = 0; grp < 12; ++grp) {

@@ -173,9 +173,15 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino64_conv(const WinoArgs a) {
     const unsigned lds_base = (unsigned)(uintptr_t)(&lds[0]);
     auto dma_round = [&](int buf, int ck, int m) {   // round m of this wave: 64 slots of chunk ck -> LDS buffer `buf`
         if (wave + 4 * m < NROUND) {                   // wave-uniform
-            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
             const int soff = ck * (WK * 4);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
+            const unsigned dst = lds_base + (unsigned)((buf * BUF + (wave + 4 * m) * 64) * 16);
+            // M0 (the LDS-DMA's wave-uniform LDS address) is the compiler's register: the asm saves and restores it, so whatever hipcc
+            // keeps there across this statement survives ("m0" cannot be named as a clobber: reserved register).
+            // k_wino42_conv and k_conv3x3_h16 use __builtin_amdgcn_raw_ptr_buffer_load_lds instead; with that builtin in THIS
+            // kernel hipcc (ROCm 7.2) silently drops the host-side launch stub of every instantiation, so the asm form stays.
+            unsigned m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "v"(voff[m]), "s"(rsrc_in), "s"(dst), "s"(soff) : "memory");
         }
     };
     auto dma_chunk = [&](int buf, int ck) {

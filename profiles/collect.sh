@@ -6,6 +6,9 @@
 set -o pipefail
 TAG=${1:-run}
 OUT=gpurun_out/prof_${TAG}
+# Always start from an empty directory: round 2's "final" summary was condensed from a directory that still held an earlier
+# run's CSVs (summarize.py then averaged two builds).  A stale tag is removed, never merged into.
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 # BENCH_ARGS: extra bench.py arguments (e.g. "--dtype f16 --batch-per-gpu 512" for BASELINE configs[4])

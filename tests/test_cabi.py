@@ -60,7 +60,9 @@ def test_oversize_image_is_an_error_not_wrong_borders():
         assert L.cid_workspace_bytes(1, h, w, ctypes.byref(n)) == 2, (h, w)
     assert L.cid_workspace_bytes(1, 2047, 2048, ctypes.byref(n)) == 0           # 2047*2048*512 < 0x7ffffff0
     assert L.cid_workspace_bytes(1, 2000, 2000, ctypes.byref(n)) == 0
-    assert L.cid_workspace_bytes(200000, 128, 128, ctypes.byref(n)) == 2         # tile decode by multiply-high: N x tiles^2 < 2^32
+    # tile decode by multiply-high: N x t^2 < 2^32 with t = the most tiles per image of any launch (128x128: 4 x 32 = 128 tiles of 32x4)
+    assert L.cid_workspace_bytes(262144, 128, 128, ctypes.byref(n)) == 2
+    assert L.cid_workspace_bytes(262143, 128, 128, ctypes.byref(n)) == 0
     h = ctypes.c_void_p()
     assert L.cid_create(ctypes.byref(h)) == 0
     fake = ctypes.c_void_p(1 << 20)                                              # aligned, never dereferenced

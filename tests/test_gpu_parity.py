@@ -678,8 +678,9 @@ def test_image_beyond_the_single_call_limit(models, weight_sets):
     x = (rng.random((1, 3, h, w), dtype=np.float32) * 2 - 1)
     y = m(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
     assert y.shape == (1, 3, h, w) and np.isfinite(y).all()
-    rows_per = (m.MAX_PIXELS_PER_CALL // w - 2 * m.STRIPE_HALO) // 8 * 8
-    for r0 in (rows_per - 8, h - 16):          # across the first seam; the bottom edge
+    rows_per = (m.MAX_PIXELS_PER_CALL // w - 2 * m.STRIPE_HALO) // 16 * 16   # the product's stripe height (generator._forward_striped)
+    assert 0 < rows_per < h
+    for r0 in (rows_per - 8, h - 16):          # a window with 8 rows on either side of the first seam; the bottom edge
         lo, hi = max(0, r0 - 40) // 4 * 4, min(h, r0 + 16 + 40)
         ref = torch_oracle.forward(weight_sets["default"], x[:, :, lo:hi, 512:768 + 64]).numpy()
         got = y[:, :, r0:r0 + 16, 512 + 32:768 + 32]

@@ -8,6 +8,8 @@ import pytest
 import torch
 
 import celebrity_image_denoiser_amd as cid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from celebrity_image_denoiser_amd import api, dist as cdist, synth
 
 
@@ -261,3 +263,35 @@ def test_winograd_f4x2_transform_constants():
         Y = A2t @ (U * V) @ A4t.T
         ref = np.array([[(d[y:y + 3, x:x + 3] * g).sum() for x in range(4)] for y in range(2)])
         assert np.abs(Y - ref).max() < 1e-12
+
+
+def test_tracked_profiles_describe_the_default_kernels():
+    """VERDICT r2 #1 / ADVICE r2: profiles/pmc_traffic.json (read by bench.py for roofline.traffic) and the latest tracked
+    rocprofv3 stats table must be profiles of the kernels the DEFAULT forward launches — the names cid_launch_kernel()
+    reports — and profiles/summarize.py's own check list must agree with the library."""
+    import ctypes
+    import glob
+    import importlib.util
+    import json
+
+    from celebrity_image_denoiser_amd import _lib
+
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.cid_create(ctypes.byref(h)) == 0
+    names = [L.cid_launch_kernel(h, i).decode() for i in range(_lib.CID_NUM_LAUNCHES)]
+    L.cid_destroy(h)
+    spec = importlib.util.spec_from_file_location("summarize", os.path.join(ROOT, "profiles", "summarize.py"))
+    summ = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(summ)
+    assert len(summ.EXPECT) == len(names)
+    for want, name in zip(summ.EXPECT, names):
+        assert want.startswith(name) or name.startswith(want), (want, name)
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for name in names:
+        hit = [k for k in traffic if k.startswith(name)]
+        assert hit and all(traffic[k] > 0 for k in hit), f"profiles/pmc_traffic.json has no entry for the default kernel {name!r}"
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_final_kernel_stats.csv")))[-1]
+    table = open(latest).read()
+    for name in names:
+        assert name in table, f"{os.path.basename(latest)} does not list the default kernel {name!r}"
