@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -360,6 +361,7 @@ hipError_t launch_wino64_z_tc(hipStream_t s, const WinoArgs& base) {
     hipLaunchKernelGGL((k_wino64_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
+int wino42_grid(int items, int nb);
 template <int TC>
 hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
     WinoArgs a = base;
@@ -368,7 +370,7 @@ hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* 
     a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino42_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_wino42_conv<128, 64, false, TC, 0, true>), dim3(wino42_grid(8 * a.tiles_per_xcd, 1)), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const float* in, int Hc, int Wc, float* zout, int N) {
@@ -397,6 +399,23 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
     return hipGetLastError();
 }
 
+// Grid of a k_wino42_conv launch with `items` work items (tile x column block, 8 * tiles_per_xcd * NB of them): the workgroups WALK
+// the items (id, id + grid, ...), so once there are more items than the chip holds at a time the grid is what is resident — two
+// workgroups per CU (LDS 68-75 KiB, <= 256 VGPRs) — rounded down to a multiple of 8 * NB: the XCD group (id % 8) and the column
+// block ((id / 8) % NB) of a workgroup then stay the same from item to item.  CID_WINO42_WG_PER_CU (development aid): 0 = one
+// item per workgroup (the round-2 behaviour), k = k workgroups per CU.
+int wino42_grid(int items, int nb) {
+    static const int per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    if (per_cu <= 0) return items;
+    const int resident = per_cu * cus / (8 * nb) * (8 * nb);
+    return resident > 0 && items > resident ? resident : items;
+}
+
 template <int CIN, int COUT, bool POOL, int TC>
 hipError_t launch_wino42_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
     WinoArgs a = base;
@@ -405,7 +424,7 @@ hipError_t launch_wino42_tc(hipStream_t s, const WinoArgs& base, const float* bl
     a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC>), dim3(8 * a.tiles_per_xcd * (COUT / WN2)), dim3(THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC>), dim3(wino42_grid(8 * a.tiles_per_xcd * (COUT / WN2), COUT / WN2)), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -31,6 +31,12 @@
 //   * epilogue: column transform in registers (6 -> 4); the row transform (4 -> 2) needs all four waves' rows: wave w takes the
 //     tile quarter r = w (tiles 4g + w, all 64 channels), the other three rows come through LDS (48 KiB, one pass); bias, ReLU,
 //     optional 2x2 max-pool, whole 256-byte pixels through wave-private staging.
+//   * (r3) a workgroup WALKS tiles: work item id = blockIdx.x, + gridDim.x, ... (cid_api.hip launches about two workgroups per CU
+//     when there are more items than that).  Chunk 0 of a tile lives in a third LDS buffer X that the exchange / staging area of
+//     the epilogue does not touch, so the NEXT tile's chunk 0 is fetched under the current tile's last chunk (its DMA offsets are
+//     formed under the last-but-one chunk) and the B ring runs on into the next tile's first quads: of the prologue that every
+//     tile used to pay (slot table -> offsets -> first DMA + B requests -> landed -> barrier: ~7k cycles next to a 25-55k main
+//     loop) only the first V build is left.  gridDim.x / 8 is a multiple of NB, so a workgroup keeps its column block.
 #pragma once
 #include "wino64_kernels.h"
 
@@ -42,11 +48,12 @@ struct W42Geom {
     static constexpr int TRW = 16 / TC;                       // tile rows per workgroup
     static constexpr int LW = 4 * TC + 2, LH = 2 * TRW + 2;   // raw halo tile, pixels
     static constexpr int QS = TC + 1;                         // pixels per (row, x mod 4) run
-    static constexpr int RS = TC == 16 ? 68 : TC == 8 ? 36 : 26;   // row stride in pixels: tile rows (2 raw rows) 8 / 4 pixels apart (mod 16)
+    static constexpr int RS = TC == 16 ? 68 : TC == 8 ? 36 : 22;   // row stride in pixels: tile rows (2 raw rows) 8 / 12 pixels apart (mod 16)
     static_assert(RS >= 4 * QS, "row holds four column planes");
     static constexpr int SLOTS = WPS * LH * RS;               // quads per chunk buffer: pixel = 4 channel-group quads + 1 pad
     static constexpr int NROUND = (SLOTS + 63) / 64, RW = (NROUND + 3) / 4;
     static constexpr int BUF = NROUND * 64;                   // buffer stride: whole DMA rounds (the last round's spare lanes write zeros)
+    static constexpr int TABQ = RW * 64;                      // quads of one DMA offset table: 4 waves x RW rounds x 64 lanes x 4 bytes
 };
 
 // Host: LDS quad s of a chunk buffer -> packed (row << 20 | column << 8 | channel group), ~0u = deliver zeros.  Padded to 4*RW rounds.
@@ -90,16 +97,26 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     constexpr int NB = COUT / WN2;
     static_assert(CIN % WK == 0 && COUT % WN2 == 0, "layer dims");
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "chunks are walked in (even, odd) buffer pairs");
-    constexpr int LDS_SLOTS_K = 3264;            // 51 KiB: 2 raw buffers + DMA offsets; later the exchange blocks (48 KiB); later store staging
-    static_assert(2 * BUF <= LDS_SLOTS_K, "LDS budget");
-    __shared__ f32x4 lds[LDS_SLOTS_K];
+    // LDS (quads of 16 bytes): buffer X (chunk 0 of a tile) and the two DMA offset tables (this tile's and the next one's), which
+    // the epilogue must not touch, come first; then the work area: raw buffers 0 / 1, later the exchange blocks (48 KiB), later
+    // store staging.  Everything the main loop reads lies below 64 KiB, so every ds_read address is one base register + a 16-bit
+    // immediate.  TC = 8: 1088 + 640 + 3072 quads = 75 KiB: two workgroups per CU.
+    constexpr int WORK = 3072, TABQ = Gm::TABQ;
+    static_assert(2 * BUF <= WORK, "LDS budget");
+    constexpr int XB = 0, TAB0 = BUF, WB = BUF + 2 * TABQ;        // buffer X, offset tables, work area
+    static_assert((WB + 2 * BUF) * 16 <= 65536, "raw buffers within reach of a 16-bit ds offset");
+    __shared__ f32x4 lds[BUF + 2 * TABQ + WORK];
+    f32x4* const ldsw = lds + WB;                                 // the work area
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto boff = [](int buf) { return buf == 2 ? XB : WB + buf * BUF; };   // LDS quad offset of raw buffer 0, 1 or X (= 2)
 
+    // work items of this workgroup: id, id + gridDim.x, ...  (item -> XCD group, tile, column block: decode_block)
+    int id = blockIdx.x;
     int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
+    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb, id)) return;
     int n, ty, tx;
     decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * (2 * TRW), x0 = tx * (4 * TC);
+    int y0 = ty * (2 * TRW), x0 = tx * (4 * TC);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,44 +127,77 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     if ((ABLATE & 256) && tid == 0) trace[0] = __builtin_readcyclecounter();
 
     // ---- LDS-DMA sources (same table format as k_wino64_conv) ----
-    const float* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
-    // per-lane byte offsets of this wave's DMA rounds, parked in the LDS beyond the two buffers (one ds_read_b32 per round
-    // instead of five registers held across the main loop)
-    unsigned* const voff_tab = reinterpret_cast<unsigned*>(lds + 2 * BUF) + wave * (RW * 64) + lane;
-    static_assert(2 * BUF * 16 + 4 * RW * 64 * 4 <= LDS_SLOTS_K * 16, "offset table fits behind the buffers");
-    {
-        unsigned ent[RW];
+    const size_t img_elems = (size_t)a.Hin * a.Win * a.in_ps;
+    auto image_rsrc = [&](int img) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)img * img_elems), (short)0, a.Hin * a.Win * a.in_ps * 4, 0x00020000);
+    };
+    // Per-lane byte offsets of this wave's DMA rounds, parked in the LDS (one ds_read_b32 per round instead of five registers
+    // held across the main loop).  Two tables: table `tpar` is the current tile's, the other one the next tile's (its chunk 0 is
+    // requested under the current tile's last chunk); they are formed at tile boundaries, where few registers are live.
+    // Wave-private: no barrier between writing and reading them.
+    unsigned* const voff_tab = reinterpret_cast<unsigned*>(lds + TAB0) + wave * (RW * 64) + lane;
+    int tpar = 0;
+    int dma_soff0 = 0;   // opaque zero, renewed per tile (tile_scalars below)
+    unsigned ent[RW];
+    auto load_slot_entries = [&]() {
 #pragma unroll
         for (int m = 0; m < RW; ++m) ent[m] = a.slot_tab[(wave + 4 * m) * 64 + lane];
+    };
+    auto write_offsets = [&](int tab, int ty0, int tx0, bool live) {   // the RW rounds of the tile at (ty0, tx0); !live: every lane delivers zeros
 #pragma unroll
         for (int m = 0; m < RW; ++m) {
             const unsigned e = ent[m];
-            const int gy = y0 - 1 + (int)(e >> 20), gx = x0 - 1 + (int)((e >> 8) & 0xfffu);
-            const bool ok = e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+            const int gy = ty0 - 1 + (int)(e >> 20), gx = tx0 - 1 + (int)((e >> 8) & 0xfffu);
+            const bool ok = live && e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
             const unsigned off = (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4);
             const unsigned keep = ok ? 0xffffffffu : 0u;
-            voff_tab[m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
+            voff_tab[tab * (TABQ * 4) + m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
         }
-    }
+    };
+    // the tile after this one (same column block: gridDim.x / 8 is a multiple of NB)
+    bool has_next;
+    int n2, y02, x02;
+    auto decode_next = [&](int from_id) {
+        int mt2, nb2, ty2, tx2;
+        has_next = decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt2, nb2, from_id + (int)gridDim.x);
+        decode_tile(mt2, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n2, ty2, tx2);
+        y02 = ty2 * (2 * TRW); x02 = tx2 * (4 * TC);
+        if (!has_next) n2 = n;                                // keep the descriptor inside the tensor; every offset is the zero sentinel
+    };
+    load_slot_entries();
+    decode_next(id);
+    write_offsets(0, y0, x0, true);
+    write_offsets(1, y02, x02, has_next);
     // LDS-DMA through the compiler's builtin (buffer_load_dwordx4 ... offen lds; M0 = the wave-uniform LDS address): hipcc then counts
     // the rounds in its vmcnt bookkeeping, so its waits for the B quads are exact (with inline asm they were one load early per round in
     // flight: +0.3 % same-box)
-    auto dma_round = [&](int buf, int ck, int m) {   // round m of this wave: 64 quads of chunk ck -> LDS buffer `buf`
-        if (wave + 4 * m < NROUND) {                   // wave-uniform
-            const int soff = ck * (WK * 4);
-            const unsigned vo = voff_tab[m * 64];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (__attribute__((address_space(3))) void*)&lds[buf * BUF + (wave + 4 * m) * 64], 16, vo, soff, 0, 0);
+    __amdgpu_buffer_rsrc_t rsrc_in = image_rsrc(n), rsrc_next = image_rsrc(n2);   // renewed at every tile boundary
+    int wave_t = wave;   // = wave, through the per-tile opaque zero: keeps the guard below a scalar compare at its place (hoisted out
+                         // of the tile loop hipcc held it as a per-lane boolean — in VGPRs, spilled)
+    auto dma_round = [&](const __amdgpu_buffer_rsrc_t& rsrc, int tab, int buf, int ck, int m) {   // round m of this wave: 64 quads of chunk ck -> LDS buffer `buf`
+        if (4 * m + 3 < NROUND || wave_t + 4 * m < NROUND) {   // wave-uniform; a run-time test only in the last, partial set of rounds
+            const int soff = dma_soff0 + ck * (WK * 4);
+            const unsigned vo = voff_tab[tab * (TABQ * 4) + m * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)&lds[boff(buf) + (wave + 4 * m) * 64], 16, vo, soff, 0, 0);
         }
     };
     auto dma_chunk = [&](int buf, int ck) {
 #pragma unroll
-        for (int m = 0; m < RW; ++m) dma_round(buf, ck, m);
+        for (int m = 0; m < RW; ++m) dma_round(rsrc_in, tpar, buf, ck, m);
     };
 
     // ---- U stream of this wave: [nb][unit][a][q = 6*e2 + b][lane][cg]: a unit of one wave is 12 KiB, a quad 1 KiB ----
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, CIN * COUT * 24 * 4, 0x00020000);
-    const int ubase = (nb * NU * 4 + wave) * 12288;   // bytes, wave-uniform
+    // `ubase` is re-derived from an opaque zero at the top of every tile iteration (tile_scalars): otherwise hipcc hoists the ~200
+    // loop-invariant scalar offsets (ubase + unit * 48 KiB + quad * 1 KiB, the chunks' DMA offsets) out of the tile loop, runs out of
+    // SGPRs (106) and spills them into VGPR lanes — in a kernel that has no VGPR to spare (measured: 39-54 spilled VGPRs).
+    const int ubase0 = (nb * NU * 4 + wave) * 12288;   // bytes, wave-uniform
+    int ubase = ubase0;
+    auto tile_scalars = [&]() {
+        int z;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        ubase = ubase0 + z; dma_soff0 = z; wave_t = wave + z;
+    };
     const int ulane = lane * 16;
     auto b_load = [&](int gu, int q) -> f32x4 {         // quad q (0..11, in the order the MFMAs use them) of unit gu
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, ubase + gu * (4 * 12288) + q * 1024, 0));
@@ -164,17 +214,17 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     // over 64 banks (MI355X_MICROARCH.md, LDS): with every lane on the SAME half of its 16-byte quad the 32 lanes of a group
     // (two channel groups g x 16 tiles) touch only every other 8-byte slot — a 2-way conflict by construction, the 33-41 %
     // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 2.  With odd channel groups on the other half the 16 tiles of g even cover
-    // the 16 even slots (10 tc mod 32, + 16 tr for TC = 8, + 8 tr for TC = 4) and those of g odd the 16 odd ones: conflict-free.
+    // the 16 even slots (10 tc mod 32, + 16 tr for TC = 8, + 24 tr for TC = 4) and those of g odd the 16 odd ones: conflict-free.
     // Unit (chunk, s2) therefore holds channels 4g + 2 (s2 ^ (g & 1)) + e2 of the chunk (pack_winograd42_u packs U to match);
     // the half flips at every unit, one v_xor per base.
     int xbase = 2 * (WPS * ((2 * tr + xrow) * RS + tc) + g) + (g & 1), ybase = 2 * (WPS * ((2 * tr + yrow) * RS + tc) + g) + (g & 1);
     auto col_off = [](int c) { return 2 * WPS * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, pixel tc + c / 4
 
-    // ---- prologue ----
+    // ---- prologue of the workgroup's first tile ----
     f32x4 bq[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) bq[q] = b_load(0, q);
-    dma_chunk(0, 0);
+    dma_chunk(2, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk 0 has landed (this wave); past the barrier: every wave's part
     __syncthreads();
 
@@ -215,23 +265,38 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) { vcur[b][0] = vnxt[b][0]; vcur[b][1] = vnxt[b][1]; }
     };
+    auto build_first_v = [&]() {                           // V of a tile's unit 0, from buffer X
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { read_col(0, c); fold_col(c); }
-    make_v(vnxt, 0);
-    make_v(vnxt, 1);
-    finish_v();
+        for (int c = 0; c < 6; ++c) { read_col(2 * XB, c); fold_col(c); }
+        make_v(vnxt, 0);
+        make_v(vnxt, 1);
+        finish_v();
+    };
+    build_first_v();
+    auto next_tile = [&]() {   // at a tile boundary: the prefetched tile becomes the current one; decode its successor and form that one's offsets
+        id += (int)gridDim.x; n = n2; y0 = y02; x0 = x02;
+        tpar ^= 1;
+        rsrc_in = rsrc_next;
+        decode_next(id);
+        rsrc_next = image_rsrc(n2);
+        write_offsets(tpar ^ 1, y02, x02, has_next);   // `ent` was requested before the epilogue
+        flip_half();           // NU - 1 builds flipped the half an odd number of times: back to unit 0's
+        build_first_v();
+    };
 
-    // Chunk ck in LDS buffer PAR: two units (s2 = 0, 1: the two channel pairs of every quad).  Unit = 12 groups of four MFMAs
-    // (k-step e2 outer, position b inner, the four channel groups innermost); under them the next unit's V is built.
+
+    // Chunk ck in LDS buffer PAR (chunk 0: buffer X): two units (s2 = 0, 1: the two channel pairs of every quad).  Unit = 12 groups of
+    // four MFMAs (k-step e2 outer, position b inner, the four channel groups innermost); under them the next unit's V is built.
     auto chunk = [&](auto first_tag, auto more_tag, auto dma_tag, auto parity_tag, int ck) {
         constexpr bool FIRST = decltype(first_tag)::value;    // chunk 0: accumulators start from a zero C operand
-        constexpr bool MORE = decltype(more_tag)::value;      // a chunk ck+1 exists
-        constexpr bool DMA = decltype(dma_tag)::value;        // a chunk ck+2 exists: fetch it into this chunk's buffer
+        constexpr bool MORE = decltype(more_tag)::value;      // a chunk ck+1 exists; else: the last chunk, under which the next tile's chunk 0 is fetched
+        constexpr bool DMA = decltype(dma_tag)::value;        // a chunk ck+2 exists: fetch it into the buffer that is free by then
         constexpr int PAR = decltype(parity_tag)::value ? 1 : 0;
+        constexpr int RB = FIRST ? 2 : PAR, OB = FIRST ? 1 : 1 - PAR, TB = FIRST ? 0 : PAR;   // read / other / DMA-target buffer
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const bool build = ((k == 0) || MORE) && !(ABLATE & 4);
-            const int nhalf = (k == 0) ? 2 * PAR * BUF : 2 * (1 - PAR) * BUF;   // the next unit: this buffer's other half, or the other buffer
+            const int nhalf = (k == 0) ? 2 * boff(RB) : 2 * boff(OB);   // the next unit: this buffer's other half, or the other buffer
             const int gu = ck * 2 + k;
             if (build) flip_half();
             if (FIRST && k == 0 && !(ABLATE & 1)) dma_chunk(1, 1);   // chunk 1 lands under unit 0
@@ -244,7 +309,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                     if (grp == 8) make_v(vnxt, 0);
                     if (grp == 10) make_v(vnxt, 1);
                 }
-                if (DMA && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(PAR, ck + 2, grp - 6);
+                if (DMA && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(rsrc_in, tpar, TB, ck + 2, grp - 6);
+                if (!MORE && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(rsrc_next, tpar ^ 1, 2, 0, grp - 6);   // next tile, chunk 0 -> X
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
                     if (FIRST && k == 0 && e2 == 0) {
@@ -254,10 +320,12 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                         acc[b][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[b][e2], bq[b][cg], acc[b][cg], 0, 0, 0);
                     }
                 }
-                // ring slot b: refilled with the quad six uses ahead (the other k-step of this unit, or the next unit's first)
+                // ring slot b: refilled with the quad six uses ahead (the other k-step of this unit, the next unit's first, or — at
+                // the end of a tile — the first quads of the next tile: same column block, so the stream simply starts over)
                 if (ABLATE & 2) {}
                 else if (grp < 6) bq[b] = b_load(gu, grp + 6);
                 else if (MORE || k == 0) bq[b] = b_load(gu + 1, grp - 6);
+                else bq[b] = b_load(0, grp - 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (build) finish_v();
@@ -272,6 +340,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     using T = std::true_type;
     using F = std::false_type;
     if ((ABLATE & 256) && tid == 0) trace[1] = __builtin_readcyclecounter();
+    for (;;) {   // ---- one tile per iteration ----
+    tile_scalars();
     chunk(T{}, T{}, T{}, F{}, 0);
     chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
     for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
@@ -289,14 +359,26 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) sum += acc[b][cg][0] + acc[b][cg][1] + acc[b][cg][2] + acc[b][cg][3];
         if (sum == 123.456f) a.out[tid] = sum;
-        return;
+        if (!has_next) break;
+        load_slot_entries();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        next_tile();
+        continue;
     }
     // ---- output transform ----
+    // Everything lane-dependent below is derived from an opaque copy of the lane id made here, per tile: otherwise hipcc hoists the
+    // epilogue's address arithmetic (staging and exchange addresses, store offsets) out of the tile loop and keeps it in VGPRs
+    // across the main loop, which has none to spare.
+    int lane_e;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane_e) : "v"(tid & 63));
+    const int lane = lane_e, m16 = lane_e & 15, g = lane_e >> 4;
     // Wave w finishes tile quarter r = w: the tiles 4g + w (g = lane >> 4) for all four channel groups.  Its bias values are
     // requested here; the column transform and the exchange cover their latency.
     float bias_v[4];
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[nb * WN2 + cg * 16 + m16];
+    if (has_next) load_slot_entries();   // for the offsets formed at the tile boundary; older than the epilogue's stores, so its wait skips them
     // step 1, in registers: mp[cg][r] = (b' = 0..3) = sum_b A4^T[b'][b] acc[b][cg][r]
     f32x4 mp[4][4];
 #pragma unroll
@@ -312,19 +394,22 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     //   Y[0] = (m0 + m1) + m2,  Y[1] = m1 - (m2 + m3)   (the F(2,3) output transform of k_wino64_conv, same order)
     auto epilogue = [&](auto wave_tag) {
         constexpr int W = decltype(wave_tag)::value;
-        __syncthreads();                                     // raw tiles are dead: LDS becomes the exchange area
+        // The next tile's chunk 0 (requested under the last chunk, into buffer X) has landed for this wave — the column transform
+        // above covered its latency, and that of the last B refills and the bias values — and past the barrier for every wave.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // raw tiles 0 / 1 are dead: their LDS becomes the exchange area
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r != W) lds[((W * 3 + (r - (r > W ? 1 : 0))) * 4 + cg) * 64 + lane] = mp[cg][r];
+                if (r != W) ldsw[((W * 3 + (r - (r > W ? 1 : 0))) * 4 + cg) * 64 + lane] = mp[cg][r];
         __syncthreads();
         f32x4 Y[4][2];                                       // [cg][a'] = the four b' of output row a'
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
             f32x4 m[4];
 #pragma unroll
-            for (int ar = 0; ar < 4; ++ar) m[ar] = (ar == W) ? mp[cg][W] : lds[((ar * 3 + (W - (W > ar ? 1 : 0))) * 4 + cg) * 64 + lane];
+            for (int ar = 0; ar < 4; ++ar) m[ar] = (ar == W) ? mp[cg][W] : ldsw[((ar * 3 + (W - (W > ar ? 1 : 0))) * 4 + cg) * 64 + lane];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 Y[cg][0][e] = (m[0][e] + m[1][e]) + m[2][e];
@@ -336,7 +421,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         // [quarter g][pixel a'*4 + b'][64 channels] (68-float rows, 16 floats between quarters: conflict-free writes), read back
         // as 16-byte channel quads: sixteen lanes write one pixel's 256 bytes.
         constexpr int STR = 68, QSTR = 8 * STR + 16;
-        float* stg = reinterpret_cast<float*>(lds) + W * (4 * QSTR);
+        float* stg = reinterpret_cast<float*>(ldsw) + W * (4 * QSTR);
         const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
         const int cbase = nb * WN2;
 #pragma unroll
@@ -422,6 +507,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         case 2: epilogue(std::integral_constant<int, 2>{}); break;
         default: epilogue(std::integral_constant<int, 3>{}); break;
     }
+    // Barrier discipline of the four instantiations above: each executes exactly three __syncthreads() on every path (the ZOUT
+    // `return` leaves the lambda after the third).  s_barrier is not PC-matched, so waves meeting at different program counters
+    // is what the hardware does anyway; what must hold — and does, by construction of the one lambda body — is the equal COUNT.
+    if (!has_next) break;                                     // workgroup-uniform
+    __syncthreads();   // every wave has left the exchange / staging area: buffers 0 / 1 may be written again
+    next_tile();
+    }   // ---- next tile ----
     if ((ABLATE & 256) && tid == 0) {
         trace[3] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
