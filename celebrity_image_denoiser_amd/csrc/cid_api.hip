@@ -361,7 +361,7 @@ hipError_t launch_wino64_z_tc(hipStream_t s, const WinoArgs& base) {
     hipLaunchKernelGGL((k_wino64_conv<128, 64, false, TC, 0, true>), dim3(8 * a.tiles_per_xcd), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
-int wino42_grid(int items, int nb);
+int wino42_grid(WinoArgs& a, int nb);
 template <int TC>
 hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
     WinoArgs a = base;
@@ -370,7 +370,8 @@ hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* 
     a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino42_conv<128, 64, false, TC, 0, true>), dim3(wino42_grid(8 * a.tiles_per_xcd, 1)), dim3(THREADS), 0, s, a);
+    const int grid = wino42_grid(a, 1);
+    hipLaunchKernelGGL((k_wino42_conv<128, 64, false, TC, 0, true>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const float* in, int Hc, int Wc, float* zout, int N) {
@@ -380,7 +381,7 @@ hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const 
     a.N = N; a.Hin = Hc; a.Win = Wc; a.in_ps = 128; a.Hc = Hc; a.Wc = Wc; a.Hs = Hc; a.Ws = Wc;
     a.out_ps = 64; a.out_coff = 0;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
-    a.rcp_x = a.rcp_xy = 0;
+    a.rcp_x = a.rcp_xy = 0; a.walk = 0;
     if (algo == CID_ALGO_WINOGRAD42) {
         a.u = blob + kBlob.u42_off[10];
         if (Wc > 16) return launch_wino42_z_tc<8>(s, a, blob, 0);
@@ -399,21 +400,24 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
     return hipGetLastError();
 }
 
-// Grid of a k_wino42_conv launch with `items` work items (tile x column block, 8 * tiles_per_xcd * NB of them): the workgroups WALK
-// the items (id, id + grid, ...), so once there are more items than the chip holds at a time the grid is what is resident — two
-// workgroups per CU (LDS 68-75 KiB, <= 256 VGPRs) — rounded down to a multiple of 8 * NB: the XCD group (id % 8) and the column
-// block ((id / 8) % NB) of a workgroup then stay the same from item to item.  CID_WINO42_WG_PER_CU (development aid): 0 = one
-// item per workgroup (the round-2 behaviour), k = k workgroups per CU.
-int wino42_grid(int items, int nb) {
+// Grid of a k_wino42_conv launch over `tiles_per_xcd` tiles per XCD group and NB column blocks.  Small launches: one workgroup
+// per (tile, column block), a.walk = 0.  Once there are more items than the chip holds at a time — two workgroups per CU (LDS
+// 75 KiB, <= 256 VGPRs) — the grid is what is resident and the workgroups WALK: a.walk = grid / 8 walkers per XCD group, each
+// taking tiles local, local + walk, ... with all NB column blocks of a tile back to back.  CID_WINO42_WG_PER_CU (development
+// aid): 0 = never walk (the round-2 behaviour), k = k workgroups per CU.
+int wino42_grid(WinoArgs& a, int nb) {
     static const int per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    if (per_cu <= 0) return items;
-    const int resident = per_cu * cus / (8 * nb) * (8 * nb);
-    return resident > 0 && items > resident ? resident : items;
+    const int items = 8 * a.tiles_per_xcd * nb;
+    const int walkers = per_cu * cus / 8;                    // per XCD group
+    a.walk = 0;
+    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers) return items;
+    a.walk = walkers;
+    return 8 * walkers;
 }
 
 template <int CIN, int COUT, bool POOL, int TC>
@@ -424,7 +428,8 @@ hipError_t launch_wino42_tc(hipStream_t s, const WinoArgs& base, const float* bl
     a.tiles_x = cdiv(a.Wc, 4 * TC); a.tiles_y = cdiv(a.Hc, 2 * TRW);
     a.tiles_total = a.N * a.tiles_x * a.tiles_y; a.tiles_per_xcd = cdiv(a.tiles_total, 8);
     a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC>), dim3(wino42_grid(8 * a.tiles_per_xcd * (COUT / WN2), COUT / WN2)), dim3(THREADS), 0, s, a);
+    const int grid = wino42_grid(a, COUT / WN2);
+    hipLaunchKernelGGL((k_wino42_conv<CIN, COUT, POOL, TC>), dim3(grid), dim3(THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -439,7 +444,7 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws;
     a.out_ps = out_ps; a.out_coff = out_coff;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
-    a.rcp_x = a.rcp_xy = 0;
+    a.rcp_x = a.rcp_xy = 0; a.walk = 0;
     if (algo == CID_ALGO_WINOGRAD42) {   // 16 tiles of 4x2 pixels per workgroup: 8 x 2 (32x4 pixels), or 4 x 4 (16x8) for rows of 16 pixels or fewer.
         // 16 x 1 (64x2 pixels) fetches 4 input rows for 2 of output: same-box 24.4k images/s against 24.8k (8 x 2) and 24.7k (4 x 4 everywhere)
         a.u = blob + kBlob.u42_off[layer];

@@ -110,10 +110,17 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto boff = [](int buf) { return buf == 2 ? XB : WB + buf * BUF; };   // LDS quad offset of raw buffer 0, 1 or X (= 2)
 
-    // work items of this workgroup: id, id + gridDim.x, ...  (item -> XCD group, tile, column block: decode_block)
-    int id = blockIdx.x;
-    int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb, id)) return;
+    // Work items of this workgroup.  blockIdx.x % 8 labels the XCD group, which owns tiles [xcd * tiles_per_xcd, + tiles_per_xcd).
+    //   a.walk == 0: one item per workgroup, (blockIdx.x / 8) = tile * NB + column block (small launches; round-2 behaviour);
+    //   a.walk  > 0: the workgroup walks tiles local, local + walk, ... of its XCD group (walk = gridDim.x / 8 walkers per group) and
+    //                computes ALL NB column blocks of a tile back to back: the tile's input is fetched from HBM once and the other
+    //                NB - 1 reads hit this XCD's L2 (with one column block per workgroup the NB readers of a tile drifted apart
+    //                and the input was fetched 2-4 times: 2.7 GB per launch for <256,256> against 0.27 GB of input).
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    int local = a.walk ? slot0 : slot0 / NB;                // tile index inside the XCD group
+    int nb = a.walk ? 0 : slot0 - local * NB;
+    int mt = xcd * a.tiles_per_xcd + local;
+    if (!(mt < a.tiles_total && local < a.tiles_per_xcd)) return;
     int n, ty, tx;
     decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
     int y0 = ty * (2 * TRW), x0 = tx * (4 * TC);
@@ -154,18 +161,27 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             voff_tab[tab * (TABQ * 4) + m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
         }
     };
-    // the tile after this one (same column block: gridDim.x / 8 is a multiple of NB)
+    // the item after this one
     bool has_next;
     int n2, y02, x02;
-    auto decode_next = [&](int from_id) {
-        int mt2, nb2, ty2, tx2;
-        has_next = decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt2, nb2, from_id + (int)gridDim.x);
-        decode_tile(mt2, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n2, ty2, tx2);
-        y02 = ty2 * (2 * TRW); x02 = tx2 * (4 * TC);
-        if (!has_next) n2 = n;                                // keep the descriptor inside the tensor; every offset is the zero sentinel
+    int nb2, local2;
+    auto decode_next = [&]() {   // the item after (local, nb)
+        n2 = n; y02 = y0; x02 = x0; local2 = local; nb2 = nb + 1;
+        has_next = a.walk != 0;
+        if (has_next && nb2 == NB) {                          // next tile of the walk
+            nb2 = 0; local2 = local + a.walk;
+            const int mt2 = xcd * a.tiles_per_xcd + local2;
+            has_next = mt2 < a.tiles_total && local2 < a.tiles_per_xcd;
+            if (has_next) {
+                int ty2, tx2;
+                decode_tile(mt2, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n2, ty2, tx2);
+                y02 = ty2 * (2 * TRW); x02 = tx2 * (4 * TC);
+            }
+        }
+        if (!has_next) nb2 = nb;                              // keeps the B prefetch of the last item inside U
     };
     load_slot_entries();
-    decode_next(id);
+    decode_next();
     write_offsets(0, y0, x0, true);
     write_offsets(1, y02, x02, has_next);
     // LDS-DMA through the compiler's builtin (buffer_load_dwordx4 ... offen lds; M0 = the wave-uniform LDS address): hipcc then counts
@@ -191,16 +207,18 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     // `ubase` is re-derived from an opaque zero at the top of every tile iteration (tile_scalars): otherwise hipcc hoists the ~200
     // loop-invariant scalar offsets (ubase + unit * 48 KiB + quad * 1 KiB, the chunks' DMA offsets) out of the tile loop, runs out of
     // SGPRs (106) and spills them into VGPR lanes — in a kernel that has no VGPR to spare (measured: 39-54 spilled VGPRs).
-    const int ubase0 = (nb * NU * 4 + wave) * 12288;   // bytes, wave-uniform
-    int ubase = ubase0;
+    int ubase = 0, ubase_next = 0;                       // this item's column block, and the next item's (its first six quads are requested under the last chunk)
     auto tile_scalars = [&]() {
         int z;
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-        ubase = ubase0 + z; dma_soff0 = z; wave_t = wave + z;
+        ubase = (nb * NU * 4 + wave) * 12288 + z;      // bytes, wave-uniform
+        ubase_next = (nb2 * NU * 4 + wave) * 12288 + z;
+        dma_soff0 = z; wave_t = wave + z;
     };
+    tile_scalars();
     const int ulane = lane * 16;
-    auto b_load = [&](int gu, int q) -> f32x4 {         // quad q (0..11, in the order the MFMAs use them) of unit gu
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, ubase + gu * (4 * 12288) + q * 1024, 0));
+    auto b_load = [&](int gu, int q, bool next_item = false) -> f32x4 {   // quad q (0..11, in the order the MFMAs use them) of unit gu
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, ulane, (next_item ? ubase_next : ubase) + gu * (4 * 12288) + q * 1024, 0));
     };
 
     // ---- row transform of this wave (F(2,3), as k_wino64_conv):  t = x + sgn*y over patch rows
@@ -274,10 +292,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     };
     build_first_v();
     auto next_tile = [&]() {   // at a tile boundary: the prefetched tile becomes the current one; decode its successor and form that one's offsets
-        id += (int)gridDim.x; n = n2; y0 = y02; x0 = x02;
+        n = n2; y0 = y02; x0 = x02; local = local2; nb = nb2;
         tpar ^= 1;
         rsrc_in = rsrc_next;
-        decode_next(id);
+        decode_next();
         rsrc_next = image_rsrc(n2);
         write_offsets(tpar ^ 1, y02, x02, has_next);   // `ent` was requested before the epilogue
         flip_half();           // NU - 1 builds flipped the half an odd number of times: back to unit 0's
@@ -325,7 +343,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 if (ABLATE & 2) {}
                 else if (grp < 6) bq[b] = b_load(gu, grp + 6);
                 else if (MORE || k == 0) bq[b] = b_load(gu + 1, grp - 6);
-                else bq[b] = b_load(0, grp - 6);
+                else bq[b] = b_load(0, grp - 6, true);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (build) finish_v();

@@ -63,6 +63,7 @@ struct WinoArgs {
     int out_ps, out_coff;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
+    int walk;                 // k_wino42_conv: 0 = one (tile, column block) per workgroup; > 0 = tile walkers per XCD group (gridDim.x / 8)
 };
 
 constexpr int WN2 = 64;       // output channels per workgroup
