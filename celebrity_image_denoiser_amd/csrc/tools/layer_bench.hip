@@ -113,12 +113,12 @@ int main(int argc, char** argv) {
     v.push_back(makew64<128, 64, false, 32, 33>("A wino64 no-dma no-barrier", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 47 + 64>("A wino64 mfma-only no-prologue-dma", N, 128, 128, inA, uA, bA, outA, poolA));
     v.push_back(makew64<128, 64, false, 32, 128>("A wino64 no-dephase", N, 128, 128, inA, uA, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 0>("A wino42 base", N, 128, 128, inA, u42A, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 1>("A wino42 no-dma", N, 128, 128, inA, u42A, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 2>("A wino42 no-B-loads", N, 128, 128, inA, u42A, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 4>("A wino42 no-V-build", N, 128, 128, inA, u42A, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 8>("A wino42 no-epilogue", N, 128, 128, inA, u42A, bA, outA, poolA));
-    v.push_back(makew42<128, 64, false, 16, 15>("A wino42 mfma-only", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 0>("A wino42 base", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 1>("A wino42 no-dma", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 2>("A wino42 no-B-loads", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 4>("A wino42 no-V-build", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 8>("A wino42 no-epilogue", N, 128, 128, inA, u42A, bA, outA, poolA));
+    v.push_back(makew42<128, 64, false, 8, 15>("A wino42 mfma-only", N, 128, 128, inA, u42A, bA, outA, poolA));
     v.push_back(makew42<256, 256, false, 8, 0>("B wino42 base", N, 32, 32, inB, u42B, bB, outB, nullptr));
     v.push_back(makew42<256, 256, false, 8, 4>("B wino42 no-V-build", N, 32, 32, inB, u42B, bB, outB, nullptr));
     v.push_back(makew42<256, 256, false, 8, 15>("B wino42 mfma-only", N, 32, 32, inB, u42B, bB, outB, nullptr));
@@ -153,24 +153,7 @@ int main(int argc, char** argv) {
                              h[(size_t)i * 8 + 3], h[(size_t)i * 8 + 6], h[(size_t)i * 8 + 4], h[(size_t)i * 8 + 5]);
         std::fclose(f);
         std::printf("trace written: %d workgroups\n", nwg);
-        {   // the same for the F(4x2) kernel (upconv1.0 shape): phase means only
-            const int nwg3 = 8 * ((N * 2 * 64 + 7) / 8);
-            unsigned long long* tr3; CK(hipMalloc(&tr3, (size_t)nwg3 * 8 * 8)); CK(hipMemset(tr3, 0, (size_t)nwg3 * 8 * 8));
-            Variant w = makew42<128, 64, false, 16, 256>("trace42", N, 128, 128, inA, u42A, bA, outA, reinterpret_cast<float*>(tr3));
-            w.run(s); CK(hipStreamSynchronize(s));
-            CK(hipMemset(tr3, 0, (size_t)nwg3 * 8 * 8));
-            w.run(s); CK(hipStreamSynchronize(s));
-            std::vector<unsigned long long> h3((size_t)nwg3 * 8);
-            CK(hipMemcpy(h3.data(), tr3, h3.size() * 8, hipMemcpyDeviceToHost));
-            double pro = 0, mainl = 0, epi = 0, drain = 0; int cnt = 0;
-            for (int i = 0; i < nwg3; ++i) {
-                const unsigned long long* t = &h3[(size_t)i * 8];
-                if (!t[0]) continue;
-                pro += t[1] - t[0]; mainl += t[2] - t[1]; epi += t[3] - t[2]; drain += t[4] - t[3]; ++cnt;
-            }
-            std::printf("wino42 trace (%d workgroups, cycles): prologue %.0f  main loop %.0f (MFMA issue per wave %d)  epilogue %.0f  store drain %.0f\n",
-                        cnt, pro / cnt, mainl / cnt, epi / cnt, drain / cnt, 128 / 8 * 48 * 32);
-        }
+        // (the F(4x2) kernel's phase trace lives in tools/w42_bench)
         {   // the same for the dominant Winograd launch (upconv1.0 shape)
             const int nwg2 = 8 * ((N * 2 * 64 + 7) / 8);
             unsigned long long* tr2; CK(hipMalloc(&tr2, (size_t)nwg2 * 16 * 8)); CK(hipMemset(tr2, 0, (size_t)nwg2 * 16 * 8));

@@ -84,7 +84,7 @@ __device__ __forceinline__ void w42_out4(const float (&m)[6], float (&y)[4]) {
 }
 
 // ABLATE (timing experiments only, tools/layer_bench; wrong results when non-zero): 1 no DMA after the prologue, 2 B quads loaded once,
-// 4 V built once, 8 no epilogue, 256 s_memtime stamps of thread 0 into a.pool (results stay correct, non-POOL layers).
+// 4 V built once, 8 no epilogue, 256 s_memtime phase sums of thread 0 into a.zout (results stay correct, non-ZOUT layers).
 template <int CIN, int COUT, bool POOL, int TC, int ABLATE = 0, bool ZOUT = false>
 __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     static_assert(!ZOUT || (COUT == 64 && !POOL), "ZOUT contracts exactly the 64 channels of the workgroup's column block");
@@ -130,8 +130,14 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row a
     const int m16 = lane & 15, g = lane >> 4;
     const int tr = m16 / TC, tc = m16 - tr * TC;
-    unsigned long long* trace = (ABLATE & 256) ? reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8 : nullptr;
-    if ((ABLATE & 256) && tid == 0) trace[0] = __builtin_readcyclecounter();
+    // ABLATE & 256 (tools/w42_bench): thread 0 sums, over the workgroup's tiles, the shader cycles spent in the main loop, the
+    // epilogue and the tile boundary, into a.zout[blockIdx.x * 8 ...] (non-ZOUT variants): start, sums, end, tile count
+    unsigned long long* trace = (ABLATE & 256) ? reinterpret_cast<unsigned long long*>(a.zout) + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long tr_start = 0, tr_main = 0, tr_epi = 0, tr_bnd = 0, tr_t = 0, tr_tiles = 0;
+    if (ABLATE & 256) tr_start = tr_t = __builtin_readcyclecounter();
+    auto tr_lap = [&](unsigned long long& acc) {
+        if (ABLATE & 256) { const unsigned long long now = __builtin_readcyclecounter(); acc += now - tr_t; tr_t = now; }
+    };
 
     // ---- LDS-DMA sources (same table format as k_wino64_conv) ----
     const size_t img_elems = (size_t)a.Hin * a.Win * a.in_ps;
@@ -357,9 +363,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    if ((ABLATE & 256) && tid == 0) trace[1] = __builtin_readcyclecounter();
     for (;;) {   // ---- one tile per iteration ----
     tile_scalars();
+    tr_lap(tr_bnd);
     chunk(T{}, T{}, T{}, F{}, 0);
     chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
     for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
@@ -369,7 +375,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     chunk(F{}, T{}, F{}, F{}, NCHUNK - 2);
     chunk(F{}, F{}, F{}, T{}, NCHUNK - 1);
 
-    if ((ABLATE & 256) && tid == 0) trace[2] = __builtin_readcyclecounter();
+    tr_lap(tr_main);
+    ++tr_tiles;
     if (ABLATE & 8) {   // keep the accumulators alive without the epilogue
         float sum = 0.f;
 #pragma unroll
@@ -414,6 +421,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         constexpr int W = decltype(wave_tag)::value;
         // The next tile's chunk 0 (requested under the last chunk, into buffer X) has landed for this wave — the column transform
         // above covered its latency, and that of the last B refills and the bias values — and past the barrier for every wave.
+        // (Waiting at the third barrier instead, and forming the next tile's offsets and first V before the boundary barrier: -0.3 %
+        // same-box, profiles/r03_ab_wino42_walk.txt.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // raw tiles 0 / 1 are dead: their LDS becomes the exchange area
 #pragma unroll
@@ -528,12 +537,13 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     // Barrier discipline of the four instantiations above: each executes exactly three __syncthreads() on every path (the ZOUT
     // `return` leaves the lambda after the third).  s_barrier is not PC-matched, so waves meeting at different program counters
     // is what the hardware does anyway; what must hold — and does, by construction of the one lambda body — is the equal COUNT.
+    tr_lap(tr_epi);
     if (!has_next) break;                                     // workgroup-uniform
     __syncthreads();   // every wave has left the exchange / staging area: buffers 0 / 1 may be written again
     next_tile();
     }   // ---- next tile ----
     if ((ABLATE & 256) && tid == 0) {
-        trace[3] = __builtin_readcyclecounter();
+        trace[0] = tr_start; trace[1] = tr_main; trace[2] = tr_epi; trace[3] = tr_bnd; trace[5] = tr_tiles;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         trace[4] = __builtin_readcyclecounter();
     }
