@@ -19,6 +19,7 @@ Extra objects on that line:
   layers        every launch: ms, executed and algorithmic TFLOP/s, GB/s, fraction of its own (mfma|hbm) roofline
   configs       (N=1 only) short legs at BASELINE.json configs[3] (B=256, 256x256, fp32) and configs[4] (B=512, fp16
                 storage): images/sec, slowest launch, parity spot check
+  hot_weights_leg, dist_world1_leg  (N=1 only) 5 steps on the He-gain weight set; RCCL communicator + weights broadcast at world size 1
   cpu_baseline  (N=1 only) the CPU oracle = the reference's forward re-stated on the ATen CPU
                 operators the reference itself calls, timed on this host's cores on a bounded sample
 """
@@ -371,12 +372,58 @@ def main():
                 sd_hot = synth.make_state_dict("hot")
                 mh = cid.load(sd_hot, device=dev, strict=True)
                 mh.compute_dtype = "f16"
-                xh_, _, _ = synth.make_batch(2, S, S, first_index=100)
+                xh_, _, _ = synth.make_batch(16, S, S, first_index=100)
                 yh_ = mh(torch.from_numpy(xh_).to(dev)).cpu().numpy()
                 res["configs"][1]["max_abs_err_hot_weights"] = float(np.abs(yh_ - torch_oracle.forward(sd_hot, xh_).numpy()).max())
+                res["configs"][1]["hot_weights_images_checked"] = 16
                 del mh
             except Exception as e:  # pragma: no cover
                 res["configs"] = {"error": str(e)[:300]}
+        if world == 1 and not f16 and S == 128 and args.weights == "default":
+            # (a) the same workload on the He-gain ("hot") weight set: the part runs within 2-4 % of its power cap on this path, so
+            # is images/s data-dependent?  (b) the N > 1 code path at the world size this box has: RCCL communicator through the
+            # C ABI + ONE ncclBroadcast of the packed blob, timed
+            try:
+                from oracle import torch_oracle
+
+                sd_hot = synth.make_state_dict("hot")
+                mh = cid.load(sd_hot, device=dev, strict=True)
+                mh.conv_algo = args.algo
+                el, lms, nf, yh2 = timed_forwards(mh, x, 5, 2)
+                refh = torch_oracle.forward(sd_hot, x_host[:2]).numpy()
+                res["hot_weights_leg"] = {"images_per_sec": round(B * 5 / el, 1), "ms_per_step": round(el / 5 * 1e3, 3), "steps": 5, "warmup": 2,
+                                          "vs_default_weights": round((B * 5 / el) / res["value"], 4),
+                                          "max_abs_err_vs_cpu_oracle": float(np.abs(yh2[:2].cpu().numpy() - refh).max()),
+                                          "note": "same batch, He-gain synthetic weights (activations up to ~5, tanh to +-0.98)"}
+                del mh, yh2
+            except Exception as e:  # pragma: no cover
+                res["hot_weights_leg"] = {"error": str(e)[:200]}
+            if not use_dist:
+                try:
+                    import socket
+
+                    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+                    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+                    t1 = time.perf_counter()
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                    t_init = time.perf_counter() - t1
+                    times, transport = [], None
+                    for _ in range(3):
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        transport = cdist.broadcast_weights(model, src=0)
+                        torch.cuda.synchronize(dev)
+                        times.append(time.perf_counter() - t1)
+                    y2 = model(x[:2])
+                    res["dist_world1_leg"] = {"transport": transport, "process_group_init_ms": round(t_init * 1e3, 2),
+                                              "broadcast_ms_first": round(times[0] * 1e3, 2), "broadcast_ms_best": round(min(times) * 1e3, 2),
+                                              "blob_bytes": int(model.pack_weights().numel()),
+                                              "forward_after_broadcast_bit_equal": bool(torch.equal(y2, y[:2])),
+                                              "note": "world_size 1 on this box: communicator set-up (cid_comm_*) + ncclBroadcast issued by libcid.so + "
+                                                      "communicator teardown per call; the forward itself has no collective"}
+                    dist.destroy_process_group()
+                except Exception as e:  # pragma: no cover
+                    res["dist_world1_leg"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         emit(res)

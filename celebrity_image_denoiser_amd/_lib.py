@@ -38,6 +38,8 @@ SYMBOLS = {
                                _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "cid_forward_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                   _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "cid_forward_padded": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                      _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "cid_forward_timed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_float)]),
     "cid_timing_begin": (_c.c_int, [_c.c_void_p, _c.c_int]),

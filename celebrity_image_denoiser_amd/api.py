@@ -150,8 +150,9 @@ def serve_u8(model: DenoiseGenerator, images_u8: torch.Tensor, pad_divisor: int 
     """The reference server's denoise path for images of ANY size (app.py:378-385, 400-406, 433-435, 471-480):
     pad the uint8 image with black to a multiple of `pad_divisor` (transforms.Pad(fill=0), i.e. -1 after
     normalisation), normalise, run the network, map back to uint8, crop the padding off again.
-    images_u8: uint8 [N,H,W,3] (host or GPU) -> uint8 [N,H,W,3], same place.  The pad and the crop are device
-    memory copies; everything numeric runs in the fused-u8 kernels (forward_u8)."""
+    images_u8: uint8 [N,H,W,3] (host or GPU) -> uint8 [N,H,W,3], same place.  The pad and the crop are index arithmetic inside
+    the first and the last kernel (cid_forward_padded): no padded copy of the image and no uncropped result exist.  Only an
+    image beyond one call's size limit (4,194,302 padded pixels) is padded in memory, because it is then cut into stripes."""
     if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
         raise RuntimeError("serve_u8 expects a uint8 tensor of shape [N,H,W,3]")
     dev = next(model.parameters()).device
@@ -159,10 +160,10 @@ def serve_u8(model: DenoiseGenerator, images_u8: torch.Tensor, pad_divisor: int 
     n, h, w, _ = images_u8.shape
     left, top, right, bottom = get_padding(w, h, pad_divisor)
     x = images_u8.to(dev, non_blocking=True)
-    if left or top or right or bottom:
+    if model._needs_stripes(h + top + bottom, w + left + right):
         x = torch.nn.functional.pad(x, (0, 0, left, right, top, bottom), mode="constant", value=0)
-    y = model.forward_u8(x)
-    return y[:, top:top + h, left:left + w, :].contiguous().to(src_dev)
+        return model.forward_u8(x)[:, top:top + h, left:left + w, :].contiguous().to(src_dev)
+    return model.forward_padded(x, (left, top, right, bottom), out_u8=True).to(src_dev)
 
 
 def to_unit_range(y: torch.Tensor) -> torch.Tensor:

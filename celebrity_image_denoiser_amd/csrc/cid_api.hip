@@ -390,9 +390,9 @@ hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const 
     a.slot_tab = reinterpret_cast<const unsigned*>(blob + kBlob.tab_off[Wc > 32 ? 0 : 1]);
     return Wc > 32 ? launch_wino64_z_tc<32>(s, a) : launch_wino64_z_tc<16>(s, a);
 }
-hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void* out, int N, int H, int W, bool u8) {
+hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void* out, const Window& crop, int N, int H, int W, bool u8) {
     TailZArgs a;
-    a.z = z; a.bias = bias; a.out = out; a.N = N; a.H = H; a.W = W;
+    a.z = z; a.bias = bias; a.out = out; a.crop = crop; a.N = N; a.H = H; a.W = W;
     a.blocks_per_image = cdiv(H * W, THREADS);
     a.rcp_w = tile_rcp((unsigned)W); a.rcp_blocks = tile_rcp((unsigned)a.blocks_per_image);
     if (u8) hipLaunchKernelGGL((k_conv_tail_z<true>), dim3(N * a.blocks_per_image), dim3(THREADS), 0, s, a);
@@ -512,8 +512,10 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     return hipGetLastError();
 }
 
+// (H, W) = the network input.  `src` places the caller's image inside it (the band around it is uint8 0 = -1.0 normalised), `crop`
+// is the window of the network output the caller's tensor receives; null = identity (no padding, whole output).
 int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W, void* ws, size_t ws_bytes,
-                hipStream_t s, hipEvent_t* ev /* NL+1 events or null */) {
+                hipStream_t s, hipEvent_t* ev /* NL+1 events or null */, const Window* src_win = nullptr, const Window* crop_win = nullptr) {
     if (!h) return CID_ERR_INVALID;
     if (!in || !out || !ws) return fail(h, CID_ERR_INVALID, "cid_forward: null pointer");
     if (!h->dev_blob) return fail(h, CID_ERR_STATE, "cid_forward: no device weights attached (call cid_upload_weights or cid_attach_weights)");
@@ -549,6 +551,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         HeadArgs a;
         a.in = in; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[0] : kBlob.w_off[0]); a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
         a.N = N; a.H = H; a.W = W;
+        a.src = src_win ? *src_win : Window{0, 0, H, W};
         const TileGrid g = tiles_for(N, H, W);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
         tile_groups(a);
@@ -572,24 +575,25 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     // up1: ConvT 128->64 -> cat1[:, 0:64]                                                app.py:73,96
     STEP((launch_layer<128, 64, 2>(h, s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     const bool fused_tail = fused_tail_active(h);
+    const Window crop = crop_win ? *crop_win : Window{0, 0, d.Hu1, d.Wu1};
     if (fused_tail) {
         // upconv1[0] + ReLU, with upconv1[2]'s channel contraction in its epilogue: z planes into the t4 region     app.py:75-77
         STEP(launch_upconv1_0_z(h->algo, s, blob, B[CAT1], d.Hu1, d.Wu1, B[T4], N));
         // the nine-tap shifted sum + bias + tanh, -> NCHW out                              app.py:77,103
-        STEP(launch_tail_z(s, B[T4], blob + kBlob.b_off[11], out, N, d.Hu1, d.Wu1, out_fmt == CID_FMT_U8_NHWC));
+        STEP(launch_tail_z(s, B[T4], blob + kBlob.b_off[11], out, crop, N, d.Hu1, d.Wu1, out_fmt == CID_FMT_U8_NHWC));
     } else {
     // upconv1[0] + ReLU                                                                  app.py:75-76
     STEP((launch_layer<128, 64, 0>(h, s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
     // upconv1[2] + tanh, NHWC t4 -> NCHW out                                            app.py:77,103
     if (h->dtype == CID_DTYPE_F32 && d.Wu1 <= T2_MAXW && h->tail_algo == CID_TAIL_BANDS) {   // row-band kernel: z once per pixel
         Tail2Args a;
-        a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out;
+        a.in = B[T4]; a.w = blob + kBlob.w_off[11]; a.bias = blob + kBlob.b_off[11]; a.out = out; a.crop = crop;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         tail2_plan(a);
         STEP(launch_tail2(s, a, out_fmt == CID_FMT_U8_NHWC));
     } else {   // 8x32 tiles with halo: images wider than 128 pixels, and the fp16-storage path
         TailArgs a;
-        a.in = B[T4]; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[11] : kBlob.w_off[11]); a.bias = blob + kBlob.b_off[11]; a.out = out;
+        a.in = B[T4]; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[11] : kBlob.w_off[11]); a.bias = blob + kBlob.b_off[11]; a.out = out; a.crop = crop;
         a.N = N; a.H = d.Hu1; a.W = d.Wu1;
         const TileGrid g = tiles_for(N, d.Hu1, d.Wu1);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total;
@@ -769,6 +773,30 @@ int cid_forward_ex(cid_handle_t h, const void* in, int in_fmt, void* out, int ou
     hipEvent_t* ev = nullptr;
     if (h && h->tev_used < h->tev_forwards) ev = h->tev.data() + (size_t)h->tev_used * (NL + 1);
     const int rc = run_forward(h, in, in_fmt, out, out_fmt, N, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), ev);
+    if (ev && rc == CID_OK) ++h->tev_used;
+    return rc;
+}
+
+int cid_forward_padded(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W,
+                       int pad_left, int pad_top, int pad_right, int pad_bottom, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CID_ERR_INVALID;
+    if (pad_left < 0 || pad_top < 0 || pad_right < 0 || pad_bottom < 0 || H < 1 || W < 1 || pad_left > 4096 || pad_top > 4096 || pad_right > 4096 || pad_bottom > 4096)
+        return fail(h, CID_ERR_INVALID, "cid_forward_padded: paddings must lie in [0, 4096] and the image must not be empty");
+    const long long Hp = (long long)H + pad_top + pad_bottom, Wp = (long long)W + pad_left + pad_right;
+    if (Hp > 0x7fffffff || Wp > 0x7fffffff) return fail(h, CID_ERR_SHAPE, "cid_forward_padded: padded size overflows");
+    int Ho = 0, Wo = 0;
+    if (cid_out_shape((int)Hp, (int)Wp, &Ho, &Wo) != CID_OK) return fail(h, CID_ERR_SHAPE, "cid_forward_padded: padded image smaller than 4x4 (output size is too small)");
+    // the reference crops [top, top + H) x [left, left + W) out of the network's output (app.py:474-480): that window must exist
+    if (pad_top + H > Ho || pad_left + W > Wo) {
+        char m[256];
+        std::snprintf(m, sizeof m, "cid_forward_padded: the crop window [%d+%d, %d+%d] does not fit the network output %dx%d of the padded image %lldx%lld "
+                                   "(pad to a multiple of 4, app.py:276-281)", pad_top, H, pad_left, W, Ho, Wo, Hp, Wp);
+        return fail(h, CID_ERR_SHAPE, m);
+    }
+    const Window src{pad_top, pad_left, H, W}, crop{pad_top, pad_left, H, W};
+    hipEvent_t* ev = nullptr;
+    if (h->tev_used < h->tev_forwards) ev = h->tev.data() + (size_t)h->tev_used * (NL + 1);
+    const int rc = run_forward(h, in, in_fmt, out, out_fmt, N, (int)Hp, (int)Wp, ws, ws_bytes, static_cast<hipStream_t>(stream), ev, &src, &crop);
     if (ev && rc == CID_OK) ++h->tev_used;
     return rc;
 }

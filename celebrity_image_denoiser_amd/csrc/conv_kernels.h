@@ -472,8 +472,18 @@ inline void head_step_of(int k, int& s, int& h) {
     s = h = -1;
 }
 
+// f4: the reference server pads an upload with black to a multiple of 4, runs the network on the padded image and
+// crops the padding off the result again (app.py:276-281,384-385,474-480).  Both are index arithmetic in the first and the
+// last kernel:
+//   head: the network input [H, W] is the caller's image [win.H, win.W] placed at (win.top, win.left); the band around it holds
+//         uint8 0, i.e. (0/255 - 0.5)/0.5 = -1.0 after ToTensor + Normalize (transforms.Pad(fill=0) comes first in the reference);
+//   tail: the caller's tensor [win.H, win.W] receives the window of the network output that starts at (win.top, win.left).
+// Identity: {0, 0, H, W}.
+struct Window { int top, left, H, W; };
+
 struct HeadArgs {
-    const void* in;     // fp32 NCHW [N,3,H,W], or (IN_U8) uint8 NHWC [N,H,W,3]
+    const void* in;     // fp32 NCHW [N,3,src.H,src.W], or (IN_U8) uint8 NHWC [N,src.H,src.W,3]
+    Window src;         // where the caller's image sits inside the network input [H, W]
     const float* w;     // packed [2 ns][14 steps][64 lanes] fp32 (k_conv_head) or [4 cg][64 lanes][8] halfs (k_conv_head_h16)
     const float* bias;  // [64]
     void* out;          // NHWC [N,H,W,64]: fp32 (k_conv_head) or half (k_conv_head_h16)
@@ -516,7 +526,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
     // elements carry an out-of-range offset and read as zero.  Element s = it*256 + tid of the [3][LH][34] halo patch:
     // its plane/row/column and its LDS index do not depend on the tile.
     constexpr int NS = 3 * LH * 34, NIT = (NS + THREADS - 1) / THREADS;
-    const size_t img = (size_t)a.H * a.W * 3;   // elements per image in either input format
+    const size_t img = (size_t)a.src.H * a.src.W * 3;   // elements per image in either input format
     int pc[NIT], phy[NIT], phx[NIT], lidx[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -536,16 +546,21 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
             (short)0, (int)(IN_U8 ? img : img * 4), 0x00020000);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int gy = ty0 - 1 + phy[it], gx = tx0 - 1 + phx[it];
-            const bool ok = lidx[it] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((gy * a.W + gx) * 3 + pc[it]) : (unsigned)(((pc[it] * a.H + gy) * a.W + gx) * 4);
+            const int gy = ty0 - 1 + phy[it], gx = tx0 - 1 + phx[it];          // network-input coordinates
+            const bool net = lidx[it] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const int sy = gy - a.src.top, sx = gx - a.src.left;                 // the caller's image
+            const bool ok = net && (unsigned)sy < (unsigned)a.src.H && (unsigned)sx < (unsigned)a.src.W;
+            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((sy * a.src.W + sx) * 3 + pc[it]) : (unsigned)(((pc[it] * a.src.H + sy) * a.src.W + sx) * 4);
             if (ABLATE & 1) { staged[it] = (float)tid; continue; }
+            // three kinds of element: the image; the black band the server pads with (-1.0 once normalised); the convolution's
+            // zero padding outside the network input, which applies to the NORMALISED tensor: 0, not (0/255 - 0.5)/0.5
+            const float fill = net ? -1.f : 0.f;
             if (IN_U8) {
-                // zero padding applies to the NORMALISED tensor: a padded element is 0, not (0/255 - 0.5)/0.5
                 const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_in, goff, 0, 0);
-                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : 0.f;
+                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : fill;
             } else {
-                staged[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+                const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+                staged[it] = ok ? t : fill;
             }
         }
     };
@@ -634,7 +649,8 @@ struct TailArgs {
     const void* in;     // NHWC [N,H,W,64]: fp32, or (IN_F16) half from the fp16-storage path
     const float* w;     // packed [2 chunk][4 group][64 lanes][4]  (cid_api.hip packed_index, TAIL)
     const float* bias;  // [3]
-    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
+    void* out;          // fp32 NCHW [N,3,crop.H,crop.W], or (OUT_U8) uint8 NHWC [N,crop.H,crop.W,3]
+    Window crop;        // the window of the network output [H, W] the caller's tensor receives
     int N, H, W;
     int tiles_x, tiles_y, tiles_total;
     int tiles_per_wg, groups_total, groups_per_xcd;   // a workgroup walks tiles_per_wg consecutive tiles (host: tail_groups)
@@ -787,17 +803,18 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv_tail(const TailArgs a) {
                 for (int co = 0; co < 3; ++co) o[co] += zp[co];
             }
             const int y = y0 + row, x = x0 + col;
-            if (y < a.H && x < a.W) {
+            const int cy = y - a.crop.top, cx = x - a.crop.left;       // the caller's tensor
+            if (y < a.H && x < a.W && (unsigned)cy < (unsigned)a.crop.H && (unsigned)cx < (unsigned)a.crop.W) {
                 if (OUT_U8) {
-                    unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * 3;
+                    unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.crop.H + cy) * a.crop.W + cx) * 3;
 #pragma unroll
                     for (int co = 0; co < 3; ++co) {
                         const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
                         op[co] = (unsigned char)(v * 255.0f);
                     }
                 } else {
-                    const size_t plane = (size_t)a.H * a.W;
-                    float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+                    const size_t plane = (size_t)a.crop.H * a.crop.W;
+                    float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)cy * a.crop.W + cx;
                     op[0] = tanhf(o[0]);
                     op[plane] = tanhf(o[1]);
                     op[2 * plane] = tanhf(o[2]);
@@ -845,7 +862,8 @@ struct Tail2Args {
     const float* in;    // NHWC [N,H,W,64] fp32
     const float* w;     // packed as for k_conv_tail: [2 chunk][4 group][64 lanes][4]
     const float* bias;  // [3]
-    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
+    void* out;          // fp32 NCHW [N,3,crop.H,crop.W], or (OUT_U8) uint8 NHWC [N,crop.H,crop.W,3]
+    Window crop;        // the window of the network output [H, W] the caller's tensor receives
     int N, H, W;
     int band_rows, bands_per_image, groups_total;   // host: tail2_plan
     unsigned rcp_bands;                              // ceil(2^32 / bands_per_image)
@@ -943,14 +961,16 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail2(const Tail2Args a) {
         for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(wb[ck][g]));
 
     // ---- output addressing: two buffer stores per row; lanes (and rows) with nothing to store carry an out-of-range offset ----
-    const int px = 32 * wave + i;                          // this lane's pixel (output column)
-    const size_t plane = (size_t)a.H * a.W;
+    const int px = 32 * wave + i;                          // this lane's pixel (column of the network output)
+    const int cx = px - a.crop.left;                       // ... and of the caller's tensor
+    const bool pxok = px < a.W && (unsigned)cx < (unsigned)a.crop.W;
+    const size_t plane = (size_t)a.crop.H * a.crop.W;
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
         OUT_U8 ? (void*)(static_cast<unsigned char*>(a.out) + (size_t)n * plane * 3) : (void*)(static_cast<float*>(a.out) + (size_t)n * plane * 3),
         (short)0, (int)(OUT_U8 ? plane * 3 : plane * 12), 0x00020000);
     // store 1: channel h of pixel px; store 2: channel 2 (h = 0 lanes only)
-    const unsigned ooff1 = px < a.W ? (OUT_U8 ? (unsigned)(px * 3 + h) : (unsigned)((h * plane + px) * 4)) : 0x7ffffff0u;
-    const unsigned ooff2 = (px < a.W && h == 0) ? (OUT_U8 ? (unsigned)(px * 3 + 2) : (unsigned)((2 * plane + px) * 4)) : 0x7ffffff0u;
+    const unsigned ooff1 = pxok ? (OUT_U8 ? (unsigned)(cx * 3 + h) : (unsigned)((h * plane + cx) * 4)) : 0x7ffffff0u;
+    const unsigned ooff2 = (pxok && h == 0) ? (OUT_U8 ? (unsigned)(cx * 3 + 2) : (unsigned)((2 * plane + cx) * 4)) : 0x7ffffff0u;
 
     // ---- A fragments: logical quad 2g+h of pixel i of the wave's buffer, swizzled: slot = 8 i + ((2g + h) ^ swz) = (8 i + (h ^ swz)) ^ 2g ----
     const int aslot0 = i * 8 + (h ^ ((i >> 1) & 7));
@@ -1012,16 +1032,16 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail2(const Tail2Args a) {
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(wx), "+v"(wy));
             tot[co] = (wx + wy) + bias_v[co];
         }
-        const int y = zr - 1;
-        const bool emit = y >= r0 && y < r1;               // workgroup-uniform
+        const int y = zr - 1, cy = y - a.crop.top;         // network-output row, row of the caller's tensor
+        const bool emit = y >= r0 && y < r1 && (unsigned)cy < (unsigned)a.crop.H;   // workgroup-uniform
         const float v1 = tanhf(h ? tot[1] : tot[0]), v2 = tanhf(tot[2]);
         if (OUT_U8) {
-            const int so = emit ? y * a.W * 3 : 0;
+            const int so = emit ? cy * a.crop.W * 3 : 0;
             const float q1 = fminf(fmaxf(v1 * 0.5f + 0.5f, 0.f), 1.f), q2 = fminf(fmaxf(v2 * 0.5f + 0.5f, 0.f), 1.f);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(q1 * 255.0f), rsrc_out, emit ? ooff1 : 0x7ffffff0u, so, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(q2 * 255.0f), rsrc_out, emit ? ooff2 : 0x7ffffff0u, so, 0);
         } else {
-            const int so = emit ? y * a.W * 4 : 0;
+            const int so = emit ? cy * a.crop.W * 4 : 0;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rsrc_out, emit ? ooff1 : 0x7ffffff0u, so, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rsrc_out, emit ? ooff2 : 0x7ffffff0u, so, 0);
         }
@@ -1062,7 +1082,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv_tail2(const Tail2Args a) {
 struct TailZArgs {
     const float* z;     // [N, 27, H, W]
     const float* bias;  // [3]
-    void* out;          // fp32 NCHW [N,3,H,W], or (OUT_U8) uint8 NHWC [N,H,W,3]
+    void* out;          // fp32 NCHW [N,3,crop.H,crop.W], or (OUT_U8) uint8 NHWC [N,crop.H,crop.W,3]
+    Window crop;        // the window of the network output [H, W] the caller's tensor receives
     int N, H, W;
     int blocks_per_image;   // ceil(H*W / 256)
     unsigned rcp_w, rcp_blocks;
@@ -1090,19 +1111,21 @@ __global__ void __launch_bounds__(THREADS) k_conv_tail_z(const TailZArgs a) {
             for (int co = 0; co < 3; ++co)   // plane (3*tap + co) is a scalar offset; out-of-image taps: out-of-range vector offset
                 o[co] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, (int)(((3 * ty + tx) * 3 + co) * plane * 4), 0));
         }
-    if (!inside) return;
+    const int cy = (int)y - a.crop.top, cx = (int)x - a.crop.left;   // the caller's tensor
+    if (!inside || (unsigned)cy >= (unsigned)a.crop.H || (unsigned)cx >= (unsigned)a.crop.W) return;
+    const size_t oplane = (size_t)a.crop.H * a.crop.W, op_idx = (size_t)cy * a.crop.W + cx;
     if (OUT_U8) {
-        unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)n * plane + p) * 3;
+        unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)n * oplane + op_idx) * 3;
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
             const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
             op[co] = (unsigned char)(v * 255.0f);
         }
     } else {
-        float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + p;
+        float* op = static_cast<float*>(a.out) + (size_t)n * 3 * oplane + op_idx;
         op[0] = tanhf(o[0]);
-        op[plane] = tanhf(o[1]);
-        op[2 * plane] = tanhf(o[2]);
+        op[oplane] = tanhf(o[1]);
+        op[2 * oplane] = tanhf(o[2]);
     }
 }
 

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
     float* const stg = reinterpret_cast<float*>(lds_raw + IMG_BYTES) + wave * WS_FLOATS;
 
     constexpr int NS = 3 * LH * 34, NIT = (NS + THREADS - 1) / THREADS;
-    const size_t img = (size_t)a.H * a.W * 3;   // elements per image in either input format
+    const size_t img = (size_t)a.src.H * a.src.W * 3;   // elements per image in either input format
     // element s = it*256 + tid of the [3][LH][34] halo patch: plane, row, column are recomputed per tile (a few integer operations
     // against 12 registers held across the MFMAs: this kernel sits at the 128-register step)
     auto patch = [&](int it, int& c, int& hy, int& hx) {
@@ -453,15 +453,20 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
         for (int it = 0; it < NIT; ++it) {
             int c, hy, hx;
             const bool in_patch = patch(it, c, hy, hx);
-            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-            const bool ok = in_patch && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((gy * a.W + gx) * 3 + c) : (unsigned)(((c * a.H + gy) * a.W + gx) * 4);
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;                      // network-input coordinates
+            const bool net = in_patch && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const int sy = gy - a.src.top, sx = gx - a.src.left;                 // the caller's image (conv_kernels.h, Window)
+            const bool ok = net && (unsigned)sy < (unsigned)a.src.H && (unsigned)sx < (unsigned)a.src.W;
+            const unsigned goff = !ok ? 0x7ffffff0u : IN_U8 ? (unsigned)((sy * a.src.W + sx) * 3 + c) : (unsigned)(((c * a.src.H + sy) * a.src.W + sx) * 4);
+            // the image; the black band the server pads with (-1.0 once normalised); the convolution's zero padding (0 in the
+            // NORMALISED tensor, not (0/255 - 0.5)/0.5)
+            const float fill = net ? -1.f : 0.f;
             if (IN_U8) {
-                // zero padding applies to the NORMALISED tensor: a padded element is 0, not (0/255 - 0.5)/0.5
                 const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_in, goff, 0, 0);
-                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : 0.f;
+                staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : fill;
             } else {
-                staged[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+                const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_in, goff, 0, 0));
+                staged[it] = ok ? t : fill;
             }
         }
     };
@@ -619,17 +624,18 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv_tail_h(const TailArgs a) {
             for (int co = 0; co < 3; ++co) o[co] += zp[co];
         }
         const int y = y0 + row, x = x0 + col;
-        if (y < a.H && x < a.W) {
+        const int cy = y - a.crop.top, cx = x - a.crop.left;       // the caller's tensor (conv_kernels.h, Window)
+        if (y < a.H && x < a.W && (unsigned)cy < (unsigned)a.crop.H && (unsigned)cx < (unsigned)a.crop.W) {
             if (OUT_U8) {
-                unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * 3;
+                unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)(n * a.crop.H + cy) * a.crop.W + cx) * 3;
 #pragma unroll
                 for (int co = 0; co < 3; ++co) {
                     const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
                     op[co] = (unsigned char)(v * 255.0f);
                 }
             } else {
-                const size_t plane = (size_t)a.H * a.W;
-                float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)y * a.W + x;
+                const size_t plane = (size_t)a.crop.H * a.crop.W;
+                float* op = static_cast<float*>(a.out) + (size_t)n * 3 * plane + (size_t)cy * a.crop.W + cx;
                 op[0] = tanhf(o[0]);
                 op[plane] = tanhf(o[1]);
                 op[2 * plane] = tanhf(o[2]);

@@ -14,7 +14,7 @@ struct Variant { std::string name; std::function<void(hipStream_t)> run; };
 template <int ABLATE>
 static Variant head(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int extra_lds, int tpw = 0) {
     HeadArgs a{};
-    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
+    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W; a.src = Window{0, 0, H, W};
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
     a.tiles_total = N * a.tiles_x * a.tiles_y; tile_groups(a);
     if (tpw > 0) { a.tiles_per_wg = tpw; a.groups_total = (a.tiles_total + tpw - 1) / tpw; a.groups_per_xcd = (a.groups_total + 7) / 8; }
@@ -25,7 +25,7 @@ static Variant head(const char* name, int N, int H, int W, float* in, float* w, 
 template <int ABLATE>
 static Variant tail(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int extra_lds, int tpw = 0) {
     TailArgs a{};
-    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
+    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W; a.crop = Window{0, 0, H, W};
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H;
     a.tiles_total = N * a.tiles_x * a.tiles_y; tile_groups(a);
     if (tpw > 0) { a.tiles_per_wg = tpw; a.groups_total = (a.tiles_total + tpw - 1) / tpw; a.groups_per_xcd = (a.groups_total + 7) / 8; }
@@ -37,7 +37,7 @@ static Variant tail(const char* name, int N, int H, int W, float* in, float* w, 
 template <int ABLATE>
 static Variant tail2(const char* name, int N, int H, int W, float* in, float* w, float* b, float* out, int rows = 0) {
     Tail2Args a{};
-    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W;
+    a.in = in; a.w = w; a.bias = b; a.out = out; a.N = N; a.H = H; a.W = W; a.crop = Window{0, 0, H, W};
     tail2_plan(a, rows);
     const int grid = a.groups_total;
     return {name, [=](hipStream_t s) { hipLaunchKernelGGL((k_conv_tail2<false, ABLATE>), dim3(grid), dim3(THREADS), 0, s, a); }};

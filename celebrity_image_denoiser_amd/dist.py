@@ -120,9 +120,10 @@ class WeightsComm:
             pass
 
 
-def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> str:
     """Give every rank the weights of rank `src` with ONE broadcast of the packed blob.  `src` is a GLOBAL rank, as in
     torch.distributed.broadcast; inside a sub-group it is translated to the group rank RCCL counts in.
+    Returns the transport used: "rccl-cabi" (cid_broadcast_weights), "torch-distributed" (the fallback on GPU ranks) or "host" (CPU ranks).
 
     GPU ranks: `cid_broadcast_weights` — one in-place `ncclBroadcast` (RCCL over xGMI) of the device blob, issued from
     the C ABI on the current stream; receivers attach it and refresh their nn.Parameters from it.  CPU ranks (gloo,
@@ -141,7 +142,7 @@ def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dis
         dist.broadcast(blob, src=src, group=group)
         if not is_src:
             model.adopt_packed_weights(blob, update_parameters=True)
-        return
+        return "host"
     # Transport 1: ncclBroadcast issued by libcid.so on its own communicator (cid_broadcast_weights).  Transport 2, only if
     # the first cannot be set up on some rank (no RCCL found at run time, communicator creation refused): the same bytes as
     # ONE torch.distributed.broadcast on the process group's backend (nccl = the same RCCL over xGMI).  Either way it is one
@@ -152,7 +153,7 @@ def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dis
         dist.broadcast(blob, src=src, group=group)
         if not is_src:
             model.adopt_packed_weights(blob, update_parameters=True)
-        return
+        return "torch-distributed"
     try:
         if is_src:
             blob = model.pack_weights()
@@ -167,6 +168,7 @@ def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dis
         torch.cuda.current_stream(dev).synchronize()
     finally:
         comm.close()
+    return "rccl-cabi"
 
 
 def denoise_sharded(model: DenoiseGenerator, make_shard, n_items: int, group: Optional[dist.ProcessGroup] = None):

@@ -284,6 +284,41 @@ class DenoiseGenerator(nn.Module):
                                                    n, h, w, self._ws.data_ptr(), self._ws.numel(), stream))
         return y
 
+    def forward_padded(self, x: torch.Tensor, padding, out_u8: bool, out: torch.Tensor = None) -> torch.Tensor:
+        """The reference server's pad -> network -> crop for one image size (app.py:276-281,384-385,474-480) in ONE call
+        (cid_forward_padded): `x` is the caller's UNPADDED batch, uint8 [N,H,W,3] or fp32 [N,3,H,W]; `padding` =
+        (left, top, right, bottom) as get_padding returns it; the band is black (uint8 0 = -1.0 normalised).  The result has
+        the caller's H x W: the padding never exists in memory on either side — the first kernel synthesises it, the last one
+        skips it."""
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise RuntimeError("expected a 4-d tensor: uint8 [N,H,W,3] or float32 [N,3,H,W]")
+        in_u8 = x.dtype == torch.uint8
+        if (in_u8 and x.shape[3] != 3) or (not in_u8 and (x.dtype != torch.float32 or x.shape[1] != 3)):
+            raise RuntimeError(f"expected uint8 [N,H,W,3] or float32 [N,3,H,W], got {x.dtype} {list(x.shape)}")
+        if x.device.type != "cuda":
+            raise RuntimeError("got a CPU tensor: this implementation is GPU-only; there is no CPU fallback")
+        if x.device != self._device():
+            raise RuntimeError(f"input on {x.device} but module parameters on {self._device()}")
+        left, top, right, bottom = (int(v) for v in padding)
+        n = x.shape[0]
+        h, w = (x.shape[1], x.shape[2]) if in_u8 else (x.shape[2], x.shape[3])
+        hp, wp = h + top + bottom, w + left + right
+        if n < 1:
+            raise RuntimeError("empty batch")
+        if self._needs_stripes(hp, wp):
+            raise RuntimeError(f"padded image {hp}x{wp} is beyond one call's size limit: pad on the host and use forward_fmt (stripes)")
+        L = _lib.lib()
+        self.pack_weights()
+        self._ensure_arena(n, hp, wp, x.device)
+        x = x.contiguous()
+        y = self._output(out, (n, h, w, 3) if out_u8 else (n, 3, h, w), torch.uint8 if out_u8 else torch.float32, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._cid, L.cid_forward_padded(self._cid, x.data_ptr(), _lib.CID_FMT_U8_NHWC if in_u8 else _lib.CID_FMT_F32_NCHW,
+                                                       y.data_ptr(), _lib.CID_FMT_U8_NHWC if out_u8 else _lib.CID_FMT_F32_NCHW,
+                                                       n, h, w, left, top, right, bottom, self._ws.data_ptr(), self._ws.numel(), stream))
+        return y
+
     def forward_timed(self, x: torch.Tensor):
         """forward + per-launch milliseconds from HIP events on the launch stream (measurement aid)."""
         x, y, n, h, w = self._prepare(x)

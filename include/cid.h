@@ -125,6 +125,22 @@ int cid_forward_ex(cid_handle_t h, const void* in, int in_fmt, void* out, int ou
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The reference server's handling of arbitrary upload sizes (backend/app.py:276-281 get_padding, :384-385
+ * transforms.Pad(padding, fill=0) in front of ToTensor/Normalize, :474-480 crop of the result), as index arithmetic in the
+ * first and the last kernel — no padded copy of the image and no uncropped output exist:
+ *   in   : [N,3,H,W] fp32 or [N,H,W,3] uint8 — the caller's image, UNPADDED
+ *   the network runs on [H + pad_top + pad_bottom, W + pad_left + pad_right]; the band around the image is uint8 0, i.e.
+ *          (0/255 - 0.5)/0.5 = -1.0 (for CID_FMT_F32_NCHW input the band is -1.0 as well)
+ *   out  : [N,3,H,W] fp32 or [N,H,W,3] uint8 — rows [pad_top, pad_top + H) and columns [pad_left, pad_left + W) of the
+ *          network's output; that window must exist (it does when the padded size is a multiple of 4, the reference's rule),
+ *          otherwise CID_ERR_SHAPE
+ * workspace: cid_workspace_bytes(N, H + pad_top + pad_bottom, W + pad_left + pad_right).  With all pads zero and H, W multiples
+ * of 4 this is cid_forward_ex.  Pads outside [0, 4096] -> CID_ERR_INVALID.
+ */
+int cid_forward_padded(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W,
+                       int pad_left, int pad_top, int pad_right, int pad_bottom, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Same forward, with a HIP event recorded on `stream` around every kernel launch; synchronises
  * the stream and writes the CID_NUM_LAUNCHES per-launch durations in milliseconds to launch_ms.
  * Measurement aid for bench.py's roofline object; not part of the reference surface.

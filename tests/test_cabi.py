@@ -71,6 +71,13 @@ def test_oversize_image_is_an_error_not_wrong_borders():
     assert rc == 2 and b"too large" in L.cid_last_error(h) and b"stripes" in L.cid_last_error(h)
     rc = L.cid_forward(h, fake, fake, 1, 3, 3, fake, 1 << 40, None)
     assert rc == 2 and b"too small" in L.cid_last_error(h)
+    # cid_forward_padded (the server's pad -> network -> crop in one call): the crop window must exist in the network's output
+    pad = lambda H, W, l, t, r, b: L.cid_forward_padded(h, fake, 1, fake, 1, 1, H, W, l, t, r, b, fake, 1 << 40, None)  # noqa: E731
+    assert pad(30, 45, 0, 3, 1, 0) == 2 and b"does not fit" in L.cid_last_error(h)      # 33 x 46 -> output 32 x 44
+    assert pad(37, 50, 0, 0, 0, 0) == 2                                                  # unpadded 37 x 50 -> output 36 x 48
+    assert pad(30, 45, -1, 1, 2, 1) == 1 and pad(30, 45, 1, 1, 2, 5000) == 1             # bad paddings
+    assert pad(1, 1, 0, 0, 1, 1) == 2 and b"too small" in L.cid_last_error(h)            # padded image 2 x 2
+    assert pad(2040, 2040, 4, 4, 4, 4) == 2 and b"too large" in L.cid_last_error(h)      # the PADDED size counts for the one-call limit
     L.cid_destroy(h)
 
 

@@ -415,6 +415,41 @@ def test_serve_any_size_pad_and_crop(models, golden_dir, wset):
     assert d.max() <= 1 and (d != 0).mean() <= 1e-3
 
 
+def test_padded_forward_equals_pad_in_memory_bit_for_bit(models):
+    """f4 folded into the kernels (cid_forward_padded): the first kernel synthesises the black band, the last one writes only the
+    crop window.  Property: for every caller-side format, every last-layer form and both storage types the result is, bit for
+    bit, what padding the batch in memory (uint8 0 / fp32 -1.0), running the plain forward and slicing the window out gives —
+    odd pads on all four sides, ragged tiles, a window that ends inside the last tile."""
+    m = models["hot"]
+    x, _, noisy = synth.make_batch(3, 37, 50, first_index=7100)
+    xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
+    tails = ("tiles",) if m.conv_algo == "direct" else ("fused", "bands", "tiles")
+    for pads in ((1, 1, 2, 1), (0, 3, 1, 0), (5, 2, 5, 5), (0, 0, 0, 0)):   # (left, top, right, bottom): 40x53, 40x51, 44x60 (37+7, 50+10), 37x50
+        left, top, right, bottom = pads
+        hp, wp = 37 + top + bottom, 50 + left + right
+        fits = top + 37 <= 4 * (hp // 4) and left + 50 <= 4 * (wp // 4)
+        for dtype in ("f32", "f16"):
+            for tail in tails:
+                m.compute_dtype, m.tail_algo = dtype, tail
+                try:
+                    if not fits:
+                        with pytest.raises(RuntimeError, match="does not fit"):
+                            m.forward_padded(ud, pads, out_u8=True)
+                        continue
+                    up = torch.nn.functional.pad(ud, (0, 0, left, right, top, bottom), value=0)
+                    xp = torch.nn.functional.pad(xd, (left, right, top, bottom), value=-1.0)
+                    want8 = m.forward_u8(up)[:, top:top + 37, left:left + 50, :]
+                    wantf = m(xp)[:, :, top:top + 37, left:left + 50]
+                    got8 = m.forward_padded(ud, pads, out_u8=True)
+                    gotf = m.forward_padded(xd, pads, out_u8=False)
+                    assert got8.shape == (3, 37, 50, 3) and gotf.shape == (3, 3, 37, 50)
+                    assert torch.equal(got8, want8), (pads, dtype, tail)
+                    assert torch.equal(gotf, wantf), (pads, dtype, tail)
+                    assert torch.equal(m.forward_padded(xd, pads, out_u8=True), m.forward_fmt(xp, out_u8=True)[:, top:top + 37, left:left + 50, :])
+                finally:
+                    m.compute_dtype, m.tail_algo = "f32", ("tiles" if m.conv_algo == "direct" else "fused")
+
+
 def test_hip_graph_capture_and_replay(weight_sets):
     """cid_forward only enqueues kernels (no allocation, no synchronisation), so a forward can be captured into
     a HIP graph on the caller's stream and replayed: the replay must reproduce the eager result bit for bit and
