@@ -245,9 +245,16 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     auto col_off = [](int c) { return 2 * WPS * ((c & 3) * QS + (c >> 2)); };   // patch column c of the tile: plane c mod 4, pixel tc + c / 4
 
     // ---- prologue of the workgroup's first tile ----
-    f32x4 bq[6];
+    // B ring: RING quads of lead between a refill and its use (a divisor of 12, the quads of a unit)
+#ifdef CID_W42_RING
+    constexpr int RING = CID_W42_RING;
+#else
+    constexpr int RING = 6;
+#endif
+    static_assert(RING == 6 || RING == 12, "ring = the quads of one k-step or of one unit");
+    f32x4 bq[RING];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) bq[q] = b_load(0, q);
+    for (int q = 0; q < RING; ++q) bq[q] = b_load(0, q);
     dma_chunk(2, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk 0 has landed (this wave); past the barrier: every wave's part
     __syncthreads();
@@ -295,6 +302,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         make_v(vnxt, 0);
         make_v(vnxt, 1);
         finish_v();
+#ifdef CID_W42_ASM_MFMA
+#pragma unroll
+        for (int b = 0; b < 6; ++b) asm volatile("" : "+v"(vcur[b][0]), "+v"(vcur[b][1]));
+        asm volatile("s_nop 3");
+#endif
     };
     build_first_v();
     auto next_tile = [&]() {   // at a tile boundary: the prefetched tile becomes the current one; decode its successor and form that one's offsets
@@ -337,25 +349,43 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 if (!MORE && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(rsrc_next, tpar ^ 1, 2, 0, grp - 6);   // next tile, chunk 0 -> X
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
+#ifdef CID_W42_ASM_MFMA
+                    // experiment (profiles/r03_asm_mfma_ring.txt): the accumulator tied to the destination, which hipcc's own MFMA builtins
+                    // do not do (it accumulates out of place and needs 248-256 registers for this loop; 201 with this form)
+                    if (FIRST && k == 0 && e2 == 0)
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[b][cg]) : "v"(vcur[b][e2]), "v"(bq[grp % RING][cg]));
+                    else
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[b][cg]) : "v"(vcur[b][e2]), "v"(bq[grp % RING][cg]));
+#else
                     if (FIRST && k == 0 && e2 == 0) {
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        acc[b][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[b][e2], bq[b][cg], zero, 0, 0, 0);
+                        acc[b][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[b][e2], bq[grp % RING][cg], zero, 0, 0, 0);
                     } else {
-                        acc[b][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[b][e2], bq[b][cg], acc[b][cg], 0, 0, 0);
+                        acc[b][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(vcur[b][e2], bq[grp % RING][cg], acc[b][cg], 0, 0, 0);
                     }
+#endif
                 }
                 // ring slot b: refilled with the quad six uses ahead (the other k-step of this unit, the next unit's first, or — at
                 // the end of a tile — the first quads of the next tile: same column block, so the stream simply starts over)
                 if (ABLATE & 2) {}
-                else if (grp < 6) bq[b] = b_load(gu, grp + 6);
-                else if (MORE || k == 0) bq[b] = b_load(gu + 1, grp - 6);
-                else bq[b] = b_load(0, grp - 6, true);
+                else if (grp + RING < 12) bq[grp % RING] = b_load(gu, grp + RING);
+                else if (MORE || k == 0) bq[grp % RING] = b_load(gu + 1, grp + RING - 12);
+                else bq[grp % RING] = b_load(0, grp + RING - 12, true);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (build) finish_v();
+#ifdef CID_W42_ASM_MFMA
+            // hipcc's hazard recognizer does not look inside inline asm: a VALU result needs two wait states before an MFMA reads it
+            // as SrcA.  Pin the next unit's V values here (their producers cannot sink below this point) and pad.
+#pragma unroll
+            for (int b = 0; b < 6; ++b) asm volatile("" : "+v"(vcur[b][0]), "+v"(vcur[b][1]));
+            asm volatile("s_nop 3");
+#endif
             if (MORE && k == 0) {
-                // every DMA of this wave for chunk ck+1 is older than the last six B refills
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                // every DMA of this wave for chunk ck+1 is older than the last RING B refills (its rounds were issued under the
+                // previous unit's groups 6-10, each followed by that group's refill and the twelve of this unit)
+                if (RING == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 __syncthreads();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -377,6 +407,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 
     tr_lap(tr_main);
     ++tr_tiles;
+#ifdef CID_W42_ASM_MFMA
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");   // MFMA write -> VALU read of the accumulators (up to 18 wait states for an 8-pass MFMA)
+#endif
     if (ABLATE & 8) {   // keep the accumulators alive without the epilogue
         float sum = 0.f;
 #pragma unroll
