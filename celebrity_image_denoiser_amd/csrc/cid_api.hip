@@ -403,10 +403,11 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
 // Grid of a k_wino42_conv launch over `tiles_per_xcd` tiles per XCD group and NB column blocks.  Small launches: one workgroup
 // per (tile, column block), a.walk = 0.  Once there are more items than the chip holds at a time — two workgroups per CU (LDS
 // 75 KiB, <= 256 VGPRs) — the grid is what is resident and the workgroups WALK: a.walk = grid / 8 walkers per XCD group, each
-// taking tiles local, local + walk, ... with all NB column blocks of a tile back to back.  CID_WINO42_WG_PER_CU (development
-// aid): 0 = never walk (the round-2 behaviour), k = k workgroups per CU.
+// taking tiles local, local + walk, ... with all NB column blocks of a tile back to back.  CID_WINO42_WG_PER_CU (environment) and
+// cid_debug_winograd_workgroups_per_cu (development / testing aids): 0 = never walk (the round-2 behaviour), k = k workgroups per CU.
+int g_wino42_wg_per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
 int wino42_grid(WinoArgs& a, int nb) {
-    static const int per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
+    const int per_cu = g_wino42_wg_per_cu;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
@@ -799,6 +800,12 @@ int cid_forward_padded(cid_handle_t h, const void* in, int in_fmt, void* out, in
     const int rc = run_forward(h, in, in_fmt, out, out_fmt, N, (int)Hp, (int)Wp, ws, ws_bytes, static_cast<hipStream_t>(stream), ev, &src, &crop);
     if (ev && rc == CID_OK) ++h->tev_used;
     return rc;
+}
+
+int cid_debug_winograd_workgroups_per_cu(int k) {
+    const int prev = g_wino42_wg_per_cu;
+    if (k >= 0) g_wino42_wg_per_cu = k > 2 ? 2 : k;   // two is what the kernel's LDS use (75 KiB) admits
+    return prev;
 }
 
 int cid_timing_begin(cid_handle_t h, int max_forwards) {

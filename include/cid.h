@@ -245,6 +245,13 @@ int cid_broadcast_weights(cid_handle_t h, void* comm, int root, int rank, void* 
  * kernels, so a forward enqueued after it exposes any kernel that reads LDS words it has not written.
  */
 int cid_debug_poison_lds(void* stream);
+/*
+ * Testing / measurement aid (no reference counterpart; process-wide): workgroups per CU of the Winograd F(4x2) launches.
+ * k >= 1: a launch with more (tile, column block) items than k workgroups per CU is run by that many WALKING workgroups
+ * (default 2; the kernel's LDS use admits no more).  0: every item gets its own workgroup.  Both must give the same bits.
+ * Returns the previous value; a negative argument only queries.
+ */
+int cid_debug_winograd_workgroups_per_cu(int k);
 
 #ifdef __cplusplus
 }

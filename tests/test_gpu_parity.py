@@ -450,6 +450,39 @@ def test_padded_forward_equals_pad_in_memory_bit_for_bit(models):
                     m.compute_dtype, m.tail_algo = "f32", ("tiles" if m.conv_algo == "direct" else "fused")
 
 
+def test_walking_workgroups_equal_one_item_per_workgroup(weight_sets):
+    """The Winograd F(4x2) launches WALK once they have more (tile, column block) items than two workgroups per CU: a workgroup
+    takes tiles local, local + 64, ... of its XCD group with all column blocks of a tile back to back, the next tile's first chunk
+    prefetched under the current tile's last one (wino42_kernels.h).  Property: the result is, bit for bit, that of one workgroup
+    per item — on a RAGGED case: 37 images of 100x76 = 75 tiles each, so the XCD groups hold 347 tiles, not a multiple of the 64
+    walkers, the last group is short, images straddle walkers and groups, and the quarter-resolution layers (13 tiles per image)
+    fall back to one item per workgroup inside the same forward.  Plus a batch-independence and a CPU-oracle check of the walk."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import _lib
+    from oracle import torch_oracle
+
+    L = _lib.lib()
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    x, _, _ = synth.make_batch(37, 100, 76, first_index=8100)
+    xd = torch.from_numpy(x).to("cuda:0")
+    prev = L.cid_debug_winograd_workgroups_per_cu(-1)
+    assert prev == 2
+    try:
+        walk = m(xd).clone()
+        assert L.cid_debug_winograd_workgroups_per_cu(0) == 2
+        one = m(xd).clone()
+        assert L.cid_debug_winograd_workgroups_per_cu(1) == 0          # one walker per CU: other strides, same bits
+        single = m(xd).clone()
+    finally:
+        L.cid_debug_winograd_workgroups_per_cu(prev)
+    assert torch.equal(walk, one) and torch.equal(walk, single)
+    for i in (0, 17, 36):                                            # an image alone (no walking at all) = the same image in the batch
+        assert torch.equal(m(xd[i:i + 1]), walk[i:i + 1]), i
+    ref = torch_oracle.forward(weight_sets["hot"], x[[0, 36]]).numpy()
+    assert np.abs(walk[[0, 36]].cpu().numpy() - ref).max() <= TOL
+
+
 def test_hip_graph_capture_and_replay(weight_sets):
     """cid_forward only enqueues kernels (no allocation, no synchronisation), so a forward can be captured into
     a HIP graph on the caller's stream and replayed: the replay must reproduce the eager result bit for bit and
