@@ -94,16 +94,27 @@ static void phases(const char* tag, int N, hipStream_t s) {
     std::vector<unsigned long long> h((size_t)t.grid * 8);
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     double mainl = 0, epi = 0, bnd = 0, life = 0, tiles = 0; int cnt = 0;
-    unsigned long long first = ~0ull, last = 0;
+    std::vector<double> lives;
     for (int i = 0; i < t.grid; ++i) {
         const unsigned long long* r = &h[(size_t)i * 8];
         if (!r[0]) continue;
         mainl += r[1]; epi += r[2]; bnd += r[3]; life += r[4] - r[0]; tiles += r[5]; ++cnt;
-        first = std::min(first, r[0]); last = std::max(last, r[4]);
+        lives.push_back((double)(r[4] - r[0]));
     }
+    std::sort(lives.begin(), lives.end());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s)); t.run(s); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double lsum = 0; for (double v : lives) lsum += v;
+    std::printf("%-22s life deciles (k cycles):", tag);
+    for (int d = 0; d <= 10; ++d) std::printf(" %.0f", lives[std::min(lives.size() - 1, lives.size() * d / 10)] / 1e3);
+    std::printf("  mean %.0f\n", lsum / lives.size() / 1e3);
     constexpr int NU = CIN / 8;
-    std::printf("%-26s %5d workgroups x %.1f items: per item (cycles) main loop %.0f (MFMA issue %d)  epilogue %.0f  boundary %.0f | workgroup life %.0f, launch %llu\n",
-                tag, cnt, tiles / cnt, mainl / tiles, NU * 48 * 32, epi / tiles, bnd / tiles, life / cnt, last - first);
+    // (s_memtime counters of different XCDs are not aligned: only durations inside one workgroup are compared)
+    std::printf("%-22s %5d workgroups x %.1f items: per item (cycles) main loop %.0f (MFMA issue %d)  epilogue %.0f  boundary %.0f | workgroup life min %.0f median %.0f "
+                "p95 %.0f max %.0f cycles; launch %.4f ms\n",
+                tag, cnt, tiles / cnt, mainl / tiles, NU * 48 * 32, epi / tiles, bnd / tiles, lives.front(), lives[lives.size() / 2], lives[lives.size() * 95 / 100],
+                lives.back(), ms);
 }
 
 int main(int argc, char** argv) {
