@@ -362,6 +362,8 @@ hipError_t launch_wino64_z_tc(hipStream_t s, const WinoArgs& base) {
     return hipGetLastError();
 }
 int wino42_grid(WinoArgs& a, int nb);
+extern int g_half_wg_per_cu;
+int device_cus();
 template <int TC>
 hipError_t launch_wino42_z_tc(hipStream_t s, const WinoArgs& base, const float* blob, int tab) {
     WinoArgs a = base;
@@ -406,13 +408,18 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
 // taking tiles local, local + walk, ... with all NB column blocks of a tile back to back.  CID_WINO42_WG_PER_CU (environment) and
 // cid_debug_winograd_workgroups_per_cu (development / testing aids): 0 = never walk (the round-2 behaviour), k = k workgroups per CU.
 int g_wino42_wg_per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
-int wino42_grid(WinoArgs& a, int nb) {
-    const int per_cu = g_wino42_wg_per_cu;
+int g_half_wg_per_cu = [] { const char* e = std::getenv("CID_HALF_WG_PER_CU"); return e ? std::atoi(e) : 3; }();   // k_conv3x3_h16, same meaning
+int device_cus() {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
+    return cus;
+}
+int wino42_grid(WinoArgs& a, int nb) {
+    const int per_cu = g_wino42_wg_per_cu;
+    const int cus = device_cus();
     const int items = 8 * a.tiles_per_xcd * nb;
     const int walkers = per_cu * cus / 8;                    // per XCD group
     a.walk = 0;
@@ -508,8 +515,19 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
+    a.walk = 0;
     if constexpr (MODE == 2) hipLaunchKernelGGL((k_convt_h<CIN, COUT>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
+    else {
+        // walking workgroups (conv_kernels_f16.h): three per CU (47 KiB of LDS, <= 168 VGPRs) once there are more items than that —
+        // on the layers with CIN <= 128, where an item is short beside its prologue (same-box: down1.2 -15 %, down2.0 -11 %, the
+        // CIN = 128 layers -0.3...-1.5 %).  With CIN = 256 walking LOSES 3-5 %: a tile's NB column blocks then run one after the
+        // other in one workgroup and the 174 KB halo tile of the second pass has left the XCD's L2 (96 walkers x 174 KB), while
+        // sibling workgroups dispatched back to back share one fetch (profiles/r03_ab_f16_walk.txt).
+        int grid = 8 * g.per_xcd * NB;
+        const int walkers = g_half_wg_per_cu * device_cus() / 8;
+        if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers) { a.walk = walkers; grid = 8 * walkers; }
+        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(grid), dim3(THREADS), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -805,6 +823,11 @@ int cid_forward_padded(cid_handle_t h, const void* in, int in_fmt, void* out, in
 int cid_debug_winograd_workgroups_per_cu(int k) {
     const int prev = g_wino42_wg_per_cu;
     if (k >= 0) g_wino42_wg_per_cu = k > 2 ? 2 : k;   // two is what the kernel's LDS use (75 KiB) admits
+    return prev;
+}
+int cid_debug_half_workgroups_per_cu(int k) {
+    const int prev = g_half_wg_per_cu;
+    if (k >= 0) g_half_wg_per_cu = k > 3 ? 3 : k;     // three: 47 KiB of LDS, 168 VGPRs
     return prev;
 }
 

@@ -30,6 +30,7 @@ struct GemmConvArgsH {
     int out_ps, out_coff;
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
+    int walk;                 // k_conv3x3_h16: 0 = one (tile, column block) per workgroup; > 0 = tile walkers per XCD group (gridDim.x / 8)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -241,6 +242,13 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, float* stg, f32x4 (&
 //     one tap column (12 KiB) at a time by LDS-DMA into one of two buffers — no staging registers, and the LDS stays under a
 //     third of the CU's; the halo tile of the next chunk waits in 24 registers over the chunk's last sub-step;
 //   * per sub-step the wave reads its four input rows once (8 A quads) and 12 B quads for 48 MFMAs.
+//   * (r3) walking workgroups, as k_wino42_conv: with more (tile, column block) items than three workgroups per CU the grid is what is
+//     resident and a workgroup walks tiles local, local + walk, ... of its XCD group, all NB column blocks of a tile back to back.
+//     Under the LAST sub-step of an item the next item's first B sub-chunk is fetched into B buffer 0 (free by then: the last
+//     sub-step reads buffer 1; the epilogue's staging starts behind buffer 0) and its first halo chunk into the 24 staging registers,
+//     so an item's prologue (B DMA + halo request + their HBM latency, ~5-7k cycles beside 20-40k of work) is paid once per
+//     workgroup.  Everything renewed per item (B offset, halo offsets, image descriptor) is derived from per-item opaque values, or
+//     hipcc hoists it out of the item loop into registers this 168-register kernel does not have.
 template <int CIN, int COUT, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
@@ -252,36 +260,56 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     constexpr int NB = COUT / NTILE;
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     constexpr int HALO_SLOTS = 4 * PLANE;
-    constexpr int LDS_SLOTS = HALO_SLOTS + 2 * BSUB;                      // 47,104 B -> three workgroups per CU
-    static_assert(LDS_SLOTS * 16 >= 4 * WS_FLOATS * 4, "staging must fit");
+    // LDS: [B buffer 0][B buffer 1][halo planes]; the epilogue's store staging (4 waves x WS_FLOATS floats) takes the END of it and
+    // must leave B buffer 0 alone: the next item's first B sub-chunk lands there while the epilogue runs
+    constexpr int STAGE_SLOTS = (4 * WS_FLOATS * 4 + 15) / 16;
+    constexpr int LDS_SLOTS = (BSUB + STAGE_SLOTS > 2 * BSUB + HALO_SLOTS) ? BSUB + STAGE_SLOTS : 2 * BSUB + HALO_SLOTS;   // 47.0 KiB -> three workgroups per CU
+    constexpr int HB = 2 * BSUB;                                          // first halo slot
+    static_assert(NSUB % 2 == 0, "the last sub-step must read B buffer 1");
     __shared__ f32x4 lds[LDS_SLOTS];
 
-    int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
-    int n, ty, tx;
-    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
-    const int cobase = nb * NTILE;
-
-    // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot (tid & 3) * PLANE + (tid >> 2) + 64 it
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * a.Hin * a.Win * a.in_ps), (short)0,
-                                                                             a.Hin * a.Win * a.in_ps * 2, 0x00020000);
-    unsigned goff[NLOAD];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-        const int sidx = it * THREADS + tid;
-        const int p = sidx >> 2, q = sidx & 3;
-        const int hy = p / LW, hx = p - hy * LW;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = sidx < NSLOT && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    int local = a.walk ? slot0 : slot0 / NB;                              // tile index inside the XCD group (k_wino42_conv)
+    int nb = a.walk ? 0 : slot0 - local * NB;
+    {
+        const int mt = xcd * a.tiles_per_xcd + local;
+        if (!(mt < a.tiles_total && local < a.tiles_per_xcd)) return;
     }
-    const int hbase = (tid & 3) * PLANE + (tid >> 2);
-    f32x4 pre[NLOAD];
-    auto request_halo = [&](int ck) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto uni = [](int v) { return (int)__builtin_amdgcn_readfirstlane(v); };
+
+    // ---- per-item state ----
+    int n, y0, x0;
+    {
+        int ty, tx;
+        decode_tile(xcd * a.tiles_per_xcd + local, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
+        y0 = ty * TILE_H; x0 = tx * TILE_W;
+    }
+    const size_t img_elems = (size_t)a.Hin * a.Win * a.in_ps;
+    auto image_rsrc = [&](int img) {   // base through readfirstlane: the descriptor must live in SGPRs
+        const unsigned long long p = (unsigned long long)(a.in + (size_t)img * img_elems);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
+    };
+    // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot HB + (tid & 3) * PLANE + (tid >> 2) + 64 it
+    unsigned goff[NLOAD];
+    auto halo_offsets = [&](int ty0, int tx0, int lane_id) {
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * 64, 0));
+        for (int it = 0; it < NLOAD; ++it) {
+            const int sidx = it * THREADS + lane_id;
+            const int p = sidx >> 2, q = sidx & 3;
+            const int hy = p / LW, hx = p - hy * LW;
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+            const bool ok = sidx < NSLOT && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+            goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
+        }
+    };
+    const int hbase = HB + (tid & 3) * PLANE + (tid >> 2);
+    f32x4 pre[NLOAD];
+    auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * 64, 0));
     };
     auto halo_to_lds = [&]() {
 #pragma unroll
@@ -290,48 +318,70 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     };
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
-    const int wbase = nb * NSUB * (BSUB * 16);
     const unsigned vlane = lane * 16;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_b = [&](int g) {
+    auto dma_b = [&](int wb, int g) {   // wb = byte offset of the item's column block in the packed weights
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int soff = wbase + g * (BSUB * 16) + (wave_s + 4 * j) * 1024;
-            // the compiler's builtin (not inline asm writing M0 behind its back): M0 and the vmcnt bookkeeping are hipcc's
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)&lds[HALO_SLOTS + ((g & 1) * BSUB) + (wave_s + 4 * j) * 64], 16, vlane, soff, 0, 0);
+            const int soff = wb + g * (BSUB * 16) + (wave_s + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)&lds[((g & 1) * BSUB) + (wave_s + 4 * j) * 64], 16, vlane, soff, 0, 0);
         }
     };
-#ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 stamps s_memtime at the phase boundaries into a.pool, results unchanged
+    // the item after (local, nb): the next column block of this tile, or column block 0 of the walker's next tile
+    bool has_next;
+    int n2, y02, x02, nb2, local2;
+    auto decode_next = [&]() {
+        n2 = n; y02 = y0; x02 = x0; local2 = local; nb2 = nb + 1;
+        has_next = a.walk != 0;
+        if (has_next && nb2 == NB) {
+            nb2 = 0; local2 = local + a.walk;
+            const int mt2 = xcd * a.tiles_per_xcd + local2;
+            has_next = mt2 < a.tiles_total && local2 < a.tiles_per_xcd;
+            if (has_next) {
+                int ty2, tx2;
+                decode_tile(mt2, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n2, ty2, tx2);
+                y02 = ty2 * TILE_H; x02 = tx2 * TILE_W;
+            }
+        }
+        if (!has_next) nb2 = nb;
+        n2 = uni(n2); y02 = uni(y02); x02 = uni(x02); local2 = uni(local2); nb2 = uni(nb2); has_next = uni(has_next) != 0;
+    };
+
+#ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 stamps s_memtime at the phase boundaries of its FIRST item into a.pool, results unchanged
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8;
     if (tid == 0) trace[0] = __builtin_readcyclecounter();
+    bool first_item = true;
 #endif
-    dma_b(0);
-    request_halo(0);
-    float bias_v[4];
-#pragma unroll
-    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16];
+    // ---- prologue of the workgroup's first item ----
+    __amdgpu_buffer_rsrc_t rsrc_in = image_rsrc(n);
+    halo_offsets(y0, x0, tid);
+    dma_b(nb * NSUB * (BSUB * 16), 0);
+    request_halo(rsrc_in, 0, 0);
     halo_to_lds();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to hipcc's own wait counting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // B sub-chunk 0 landed (this wave); past the barrier: every wave's part
     __syncthreads();
+    decode_next();
 
-#ifdef H16_TRACE
-    if (tid == 0) trace[1] = __builtin_readcyclecounter();
-#endif
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
     // MFMA row i of a 16-pixel group is pixel prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1): with the planes 4 (mod 16) slots
     // apart, the two k-groups that share a ds_read_b128 service group ({0-3,12-15} of one, {4-11} of the next) then cover 16
     // different slots (mod 16), and the halo stores (4 k-groups x 2 pixels per 8-lane group) are 2-way instead of 4-way.
     // Horizontal neighbours (2j, 2j+1) stay in one lane's four rows, which the pooled epilogue needs.
     const int prow = h16_prow(c16);
-    const int abase = kg * PLANE + (2 * wave) * LW + prow;                // pixel (row 2*wave, column prow) of plane kg
+    const int abase = HB + kg * PLANE + (2 * wave) * LW + prow;           // pixel (row 2*wave, column prow) of plane kg
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
+    int wbase = 0, zs = 0;                                                // this item's B offset (bytes) and an opaque zero, renewed per item
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
     auto substep = [&](auto first_tag, auto last_tag, int g, int dx) {
-        constexpr bool FIRST = decltype(first_tag)::value;    // very first sub-step: the accumulators start from zero
-        constexpr bool LAST = decltype(last_tag)::value;      // very last: nothing more to fetch
-        const f16x8* bq = ldsh + HALO_SLOTS + (g & 1) * BSUB + lane;
+        constexpr bool FIRST = decltype(first_tag)::value;    // first sub-step of an item: the accumulators start from zero
+        constexpr bool LAST = decltype(last_tag)::value;      // last one: fetch the NEXT item's first B sub-chunk and halo chunk instead
+        const f16x8* bq = ldsh + (g & 1) * BSUB + lane;
         const f16x8* aq = ldsh + abase + dx;
-        if (!LAST) dma_b(g + 1);
+        if (!LAST) dma_b(wbase, g + 1);
+        else {                                                // B first: the halo loads behind it in the queue then vouch for it
+            dma_b(nb2 * NSUB * (BSUB * 16) + zs, 0);
+            halo_offsets(y02, x02, tid + zs);
+            request_halo(image_rsrc(n2), 0, zs);
+        }
         f16x8 ar[4][2], bf[3][4];
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) bf[0][cg] = bq[cg * 64];
@@ -375,38 +425,61 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     static_assert(NCHUNK >= 2, "first and last chunk are separate instantiations");
     using T = std::true_type;
     using F = std::false_type;
-    substep(T{}, F{}, 0, 0); seam();
-    substep(F{}, F{}, 1, 1); seam();
-    request_halo(1);
-    substep(F{}, F{}, 2, 2); chunk_seam();
-    for (int ck = 1; ck + 1 < NCHUNK; ++ck) {
-        substep(F{}, F{}, 3 * ck, 0); seam();
-        substep(F{}, F{}, 3 * ck + 1, 1); seam();
-        request_halo(ck + 1);
-        substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam();
-    }
-    substep(F{}, F{}, NSUB - 3, 0); seam();
-    substep(F{}, F{}, NSUB - 2, 1); seam();
-    substep(F{}, T{}, NSUB - 1, 2);
+    for (;;) {   // ---- one item per iteration ----
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+        wbase = nb * NSUB * (BSUB * 16) + zs;
+        const int cobase = nb * NTILE;
+        float bias_v[4];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16 + zs];
+#ifdef H16_TRACE
+        if (tid == 0 && first_item) trace[1] = __builtin_readcyclecounter();
+#endif
+        substep(T{}, F{}, 0, 0); seam();
+        substep(F{}, F{}, 1, 1); seam();
+        request_halo(rsrc_in, 1, zs);
+        substep(F{}, F{}, 2, 2); chunk_seam();
+        for (int ck = 1; ck + 1 < NCHUNK; ++ck) {
+            substep(F{}, F{}, 3 * ck, 0); seam();
+            substep(F{}, F{}, 3 * ck + 1, 1); seam();
+            request_halo(rsrc_in, ck + 1, zs);
+            substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam();
+        }
+        substep(F{}, F{}, NSUB - 3, 0); seam();
+        substep(F{}, F{}, NSUB - 2, 1); seam();
+        substep(F{}, T{}, NSUB - 1, 2);
 
 #ifdef H16_TRACE
-    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
-    if (tid == 0) trace[2] = __builtin_readcyclecounter();
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
+        if (tid == 0 && first_item) trace[2] = __builtin_readcyclecounter();
 #endif
-    __syncthreads();   // the store staging reuses the operand LDS
-    h16_epilogue<COUT, MODE>(a, reinterpret_cast<float*>(lds) + wave * WS_FLOATS, acc, bias_v, n, y0, x0, wave, lane, cobase);
+        __syncthreads();   // the store staging reuses the halo planes and B buffer 1
+        {
+            int lane_e;    // opaque copy of the lane id: keeps the epilogue's address arithmetic out of the item loop's registers
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lane_e) : "v"(tid & 63));
+            h16_epilogue<COUT, MODE>(a, reinterpret_cast<float*>(lds + (LDS_SLOTS - STAGE_SLOTS)) + wave * WS_FLOATS, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
+        }
 #ifdef H16_TRACE
-    if (tid == 0) {
-        trace[3] = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        trace[4] = __builtin_readcyclecounter();
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        trace[5] = hwid; trace[6] = xcc;
-    }
+        if (tid == 0 && first_item) {
+            trace[3] = __builtin_readcyclecounter();
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trace[5] = hwid; trace[6] = xcc;
+            trace[4] = __builtin_readcyclecounter();
+        }
+        first_item = false;
 #endif
+        if (!has_next) break;                                  // workgroup-uniform
+        // ---- item boundary: the prefetched item becomes the current one ----
+        n = n2; y0 = y02; x0 = x02; local = local2; nb = nb2;
+        rsrc_in = image_rsrc(n);
+        __syncthreads();   // every wave has left the staging area: the halo planes may be written again
+        halo_to_lds();     // its loads are younger than the B DMA issued with them: their arrival vouches for B buffer 0 as well
+        decode_next();
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ void run(int N, int H, int W, bool zero) {
     CK(hipMalloc(&din, in_n * 2)); CK(hipMalloc(&dw, w_n * 2)); CK(hipMalloc(&dout, out_n * 2)); CK(hipMalloc(&dbias, COUT * 4));
     CK(hipMemcpy(din, hin.data(), in_n * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), w_n * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dbias, 0, COUT * 4));
-    GemmConvArgsH a;
+    GemmConvArgsH a{};
     a.in = din; a.w = dw; a.bias = dbias; a.out = dout;
     a.N = N; a.Hin = H; a.Win = W; a.in_ps = CIN; a.Hc = H; a.Wc = W; a.Hs = H; a.Ws = W; a.out_ps = COUT; a.out_coff = 0;
     a.tiles_x = (W + TILE_W - 1) / TILE_W; a.tiles_y = (H + TILE_H - 1) / TILE_H; a.tiles_total = N * a.tiles_x * a.tiles_y;

@@ -252,6 +252,8 @@ int cid_debug_poison_lds(void* stream);
  * Returns the previous value; a negative argument only queries.
  */
 int cid_debug_winograd_workgroups_per_cu(int k);
+/* The same for the 3x3 launches of the fp16-storage path (k_conv3x3_h16): default 3 workgroups per CU, 0 = one item per workgroup. */
+int cid_debug_half_workgroups_per_cu(int k);
 
 #ifdef __cplusplus
 }

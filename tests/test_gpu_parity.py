@@ -483,6 +483,37 @@ def test_walking_workgroups_equal_one_item_per_workgroup(weight_sets):
     assert np.abs(walk[[0, 36]].cpu().numpy() - ref).max() <= TOL
 
 
+def test_walking_workgroups_fp16_equal_one_item_per_workgroup(weight_sets):
+    """The 3x3 launches of the fp16-storage path walk too (k_conv3x3_h16: next item's first B sub-chunk and halo chunk fetched under
+    the last sub-step).  Same property on the same ragged case: three / one walker per CU and one workgroup per item give the same
+    bits; plus the path's stated tolerance against the CPU oracle."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import _lib
+    from oracle import torch_oracle
+
+    L = _lib.lib()
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    m.compute_dtype = "f16"
+    x, _, _ = synth.make_batch(37, 100, 76, first_index=8100)
+    xd = torch.from_numpy(x).to("cuda:0")
+    prev = L.cid_debug_half_workgroups_per_cu(-1)
+    assert prev == 3
+    try:
+        walk = m(xd).clone()
+        assert L.cid_debug_half_workgroups_per_cu(0) == 3
+        one = m(xd).clone()
+        assert L.cid_debug_half_workgroups_per_cu(1) == 0
+        single = m(xd).clone()
+    finally:
+        L.cid_debug_half_workgroups_per_cu(prev)
+    assert torch.equal(walk, one) and torch.equal(walk, single)
+    for i in (0, 36):
+        assert torch.equal(m(xd[i:i + 1]), walk[i:i + 1]), i
+    ref = torch_oracle.forward(weight_sets["hot"], x[[0, 36]]).numpy()
+    assert np.abs(walk[[0, 36]].cpu().numpy() - ref).max() <= 5e-3
+
+
 def test_hip_graph_capture_and_replay(weight_sets):
     """cid_forward only enqueues kernels (no allocation, no synchronisation), so a forward can be captured into
     a HIP graph on the caller's stream and replayed: the replay must reproduce the eager result bit for bit and
