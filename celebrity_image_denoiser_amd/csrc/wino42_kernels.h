@@ -450,6 +450,24 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         }
     // step 2: the rows of the three other waves through LDS — block (row a, consumer w != a, cg): 64 lanes of 16 bytes (48 KiB in all) —
     //   Y[0] = (m0 + m1) + m2,  Y[1] = m1 - (m2 + m3)   (the F(2,3) output transform of k_wino64_conv, same order)
+    // Output descriptors of this item's image.  Stores go through raw buffer stores: per pass the tile, its row and its first column
+    // are compile-time or scalar (they follow from the pass number and the wave), so the address is ONE per-lane offset, formed once per
+    // item, plus a scalar offset per store — the round-2 form decoded tile and pixel per lane and per store (~210 integer VALU
+    // instructions per item and wave, a quarter of them quarter-rate 32/64-bit multiplies, on ALUs the fp32 MFMA stream shares).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // 16-byte buffer store with a scalar offset, and its data registers kept untouched for four more wait states.  Found this round:
+    // hipcc (ROCm 7.2) lets a VALU instruction overwrite the first data register of a buffer_store_dwordx4 ... s<soffset> offen one
+    // instruction after it (LLVM's hazard table exempts the register-soffset form), and gfx950 then stores the NEW value: element 0 of
+    // the quad was wrong, run to run, in the pooled tensor (profiles/r03_store_hazard.txt).  The empty asm keeps `v` alive across an s_nop 3.
+    auto store16 = [](f32x4 v, const __amdgpu_buffer_rsrc_t& rsrc, unsigned vo, unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, soff, 0);
+        asm volatile("s_nop 3" ::"v"(v) : "memory");
+    };
+    auto out_rsrc = [&](const float* base, size_t elems_before, int elems) {
+        const unsigned long long p = (unsigned long long)(base + elems_before);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, elems * 4, 0x00020000);
+    };
     auto epilogue = [&](auto wave_tag) {
         constexpr int W = decltype(wave_tag)::value;
         // The next tile's chunk 0 (requested under the last chunk, into buffer X) has landed for this wave — the column transform
@@ -520,25 +538,35 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 }
             // lane (column j = i32, half h) holds z[pixel (r&3) + 8*(r>>2) + 4*h][j]: registers 4q..4q+3 are the four pixels b' = 0..3
             // of row a' = h of tile 4q + W — one 16-byte store each into plane j
-            if (i32 < 27) {
+            {
+                const __amdgpu_buffer_rsrc_t rz = out_rsrc(a.zout, (size_t)n * 27 * a.Hs * a.Ws, 27 * a.Hs * a.Ws);
+                const unsigned lane_off = (unsigned)(((i32 * a.Hs + h) * a.Ws) * 4);       // plane i32, row offset h
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;
-                    const int yy = y0 + 2 * ttr + h, xx = x0 + 4 * ttc;
-                    if (yy < a.Hs && xx < a.Ws)
-                        *reinterpret_cast<f32x4*>(a.zout + (((size_t)n * 27 + i32) * a.Hs + yy) * a.Ws + xx) = f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]};
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;          // compile-time
+                    const int yb = y0 + 2 * ttr, xx = x0 + 4 * ttc;                             // scalar
+                    const unsigned soff = xx < a.Ws ? (unsigned)((yb * a.Ws + xx) * 4) : 0x7ffffff0u;
+                    const unsigned vo = (i32 < 27 && yb + h < a.Hs) ? lane_off : 0x7ffffff0u;
+                    store16(f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]}, rz, vo, soff);
                 }
             }
             return;
         }
+        {   // pass `it`: pixels (it & 1) * 4 + l4 of tile quarter it >> 1 (l4 = lane >> 4: the column inside the tile) x 16 channel quads
+            const int l4 = lane >> 4, q16 = lane & 15;
+            const float* rd = stg + l4 * STR + 4 * q16;
+            const __amdgpu_buffer_rsrc_t ro = out_rsrc(a.out, (size_t)n * a.Hs * a.Ws * a.out_ps, a.Hs * a.Ws * a.out_ps);
+            const unsigned lane_off = (unsigned)((l4 * a.out_ps + a.out_coff + cbase + 4 * q16) * 4);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {                     // pass `it`: 4 pixels x 16 channel quads
-            const int pe = it * 4 + (lane >> 4), qt = pe >> 3, px = pe & 7, q16 = lane & 15;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q16);
-            const int tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;
-            const int yy = y0 + 2 * ttr + (px >> 2), xx = x0 + 4 * ttc + (px & 3);
-            if (yy < a.Hs && xx < a.Ws)
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hs + yy) * a.Ws + xx) * a.out_ps + a.out_coff + cbase + 4 * q16) = v;
+            for (int it = 0; it < 8; ++it) {
+                const int qt = it >> 1, hi = it & 1, tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;   // compile-time
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + qt * QSTR + hi * 4 * STR);
+                const int yy = y0 + 2 * ttr + hi, xb = x0 + 4 * ttc;                                             // scalar
+                const unsigned soff = yy < a.Hs ? (unsigned)(((yy * a.Ws + xb) * a.out_ps) * 4) : 0x7ffffff0u;
+                const unsigned vo = xb + l4 < a.Ws ? lane_off : 0x7ffffff0u;
+                store16(v, ro, vo, soff);
+            }
         }
         if (POOL) {
             wave_lds_fence();
@@ -550,14 +578,22 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                     stg[g * QSTR + pb * STR + cg * 16 + m16] = fmaxf(mx + bias_v[cg], 0.f);
                 }
             wave_lds_fence();
+            {   // 4 quarters x 2 pooled pixels x 16 channel quads: pass `it` covers quarters 2 it + (l4 >> 1), pooled pixel l4 & 1
+                const int l4 = lane >> 4, q16 = lane & 15;
+                const float* rd = stg + (l4 >> 1) * QSTR + (l4 & 1) * STR + 4 * q16;
+                const __amdgpu_buffer_rsrc_t rp = out_rsrc(a.pool, (size_t)n * Hp * Wp * COUT, Hp * Wp * COUT);
+                const int tile0 = 4 * (l4 >> 1) + W, ttr0 = tile0 / TC, ttc0 = tile0 - ttr0 * TC;
+                const int pyl = ttr0, pxl = 2 * ttc0 + (l4 & 1);
+                const unsigned lane_off = (unsigned)(((pyl * Wp + pxl) * COUT + cbase + 4 * q16) * 4);
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {                 // 4 quarters x 2 pooled pixels x 16 channel quads
-                const int pe = it * 4 + (lane >> 4), qt = pe >> 1, px = pe & 1, q16 = lane & 15;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + qt * QSTR + px * STR + 4 * q16);
-                const int tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;
-                const int py = (y0 >> 1) + ttr, pxx = (x0 >> 1) + 2 * ttc + px;
-                if (py < Hp && pxx < Wp)
-                    *reinterpret_cast<f32x4*>(a.pool + ((size_t)(n * Hp + py) * Wp + pxx) * COUT + cbase + 4 * q16) = v;
+                for (int it = 0; it < 2; ++it) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rd + it * 2 * QSTR);
+                    const int dr = TC <= 8 ? it * (8 / TC) : 0, dc = TC <= 8 ? 0 : it * 16;
+                    const int pyb = (y0 >> 1) + dr, pxb = (x0 >> 1) + dc;
+                    const unsigned soff = (unsigned)(((pyb * Wp + pxb) * COUT) * 4);
+                    const unsigned vo = (pyb + pyl < Hp && pxb + pxl < Wp) ? lane_off : 0x7ffffff0u;
+                    store16(v, rp, vo, soff);
+                }
             }
         }
     };
