@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     unsigned* const voff_tab = reinterpret_cast<unsigned*>(lds + TAB0) + wave * (RW * 64) + lane;
     int tpar = 0;
     int dma_soff0 = 0;   // opaque zero, renewed per tile (tile_scalars below)
+    const int in_ps_log2 = __builtin_ctz((unsigned)a.in_ps);   // in_ps is a power of two (host: 64, 128, 256)
     unsigned ent[RW];
     auto load_slot_entries = [&]() {
 #pragma unroll
@@ -162,7 +163,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             const unsigned e = ent[m];
             const int gy = ty0 - 1 + (int)(e >> 20), gx = tx0 - 1 + (int)((e >> 8) & 0xfffu);
             const bool ok = live && e != ~0u && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-            const unsigned off = (unsigned)(((gy * a.Win + gx) * a.in_ps + (int)(e & 0xffu) * 4) * 4);
+            // full-rate arithmetic only (this runs once per tile, on ALUs the fp32 MFMAs share): a 24-bit multiply (gy, Win < 2^22: one call's
+            // image has < 2^22 pixels) and a shift by log2(in_ps) (64, 128 or 256 channels) instead of two quarter-rate 32-bit multiplies
+            const unsigned off = ((unsigned)(__umul24((unsigned)gy, (unsigned)a.Win) + gx) << (in_ps_log2 + 2)) + (e & 0xffu) * 16u;
             const unsigned keep = ok ? 0xffffffffu : 0u;
             voff_tab[tab * (TABQ * 4) + m * 64] = (off & keep) | (0x7ffffff0u & ~keep);
         }
