@@ -483,6 +483,42 @@ def test_walking_workgroups_equal_one_item_per_workgroup(weight_sets):
     assert np.abs(walk[[0, 36]].cpu().numpy() - ref).max() <= TOL
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_walking_full_size_every_stage_bit_equal_and_stable(weight_sets, dtype):
+    """Full-size form of the two tests around it (64 images of 128x128: every walking launch takes several tiles per workgroup),
+    stage by stage and repeated: every stored stage of the walking forward equals, bit for bit, that of the one-item-per-workgroup
+    forward, three times in a row.  This is the comparison that located round 3's store-data hazard (pooled tensor, element 0 of
+    four channel quads, run to run: profiles/r03_store_hazard.txt)."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import _lib
+
+    L = _lib.lib()
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    m.compute_dtype = dtype
+    x, _, _ = synth.make_batch(64, 128, 128, first_index=8300)
+    xd = torch.from_numpy(x).to("cuda:0")
+    stages = ["down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1"]
+    knob = L.cid_debug_winograd_workgroups_per_cu if dtype == "f32" else L.cid_debug_half_workgroups_per_cu
+    prev = knob(-1)
+
+    def run(k):
+        knob(k)
+        y = m(xd).clone()
+        torch.cuda.synchronize()
+        return y, {s: m.stage_output(s, 64, 128, 128).clone() for s in stages}
+
+    try:
+        y0, s0 = run(0)
+        for rep in range(3):
+            y1, s1 = run(prev)
+            for s in stages:
+                assert torch.equal(s0[s], s1[s]), (rep, s, int((s0[s] != s1[s]).sum()))
+            assert torch.equal(y0, y1), rep
+    finally:
+        knob(prev)
+
+
 def test_walking_workgroups_fp16_equal_one_item_per_workgroup(weight_sets):
     """The 3x3 launches of the fp16-storage path walk too (k_conv3x3_h16: next item's first B sub-chunk and halo chunk fetched under
     the last sub-step).  Same property on the same ragged case: three / one walker per CU and one workgroup per item give the same

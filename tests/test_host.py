@@ -295,3 +295,26 @@ def test_tracked_profiles_describe_the_default_kernels():
     table = open(latest).read()
     for name in names:
         assert name in table, f"{os.path.basename(latest)} does not list the default kernel {name!r}"
+
+
+def test_no_unpadded_store_data_hazard_in_the_kernels(tmp_path):
+    """Round 3 found that hipcc (ROCm 7.2) lets a VALU instruction overwrite the first data register of a
+    `buffer_store_dwordx4 ... s<soffset> offen` one instruction after it, and that gfx950 then stores the new value
+    (profiles/r03_store_hazard.txt).  The product's stores of that form hold their data registers across an s_nop 3 (store16 in
+    wino42_kernels.h); csrc/tools/store_hazard_check.py scans the generated ISA of EVERY kernel for the pattern.  Cross-compiles the
+    device code (no GPU needed, about a minute)."""
+    import shutil
+    import subprocess
+    import sys
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available: the ISA cannot be generated here")
+    csrc = os.path.join(ROOT, "celebrity_image_denoiser_amd", "csrc")
+    asm = os.path.join(tmp_path, "cid_kernels.s")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fno-slp-vectorize", "--offload-arch=gfx950", "--offload-device-only", "-S",
+                           "-o", asm, os.path.join(csrc, "cid_api.hip")], cwd=csrc, stderr=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(csrc, "tools", "store_hazard_check.py"), asm], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    n = int(out.stdout.split(":")[1].split()[0])
+    assert n >= 100, out.stdout          # the scan did see the Winograd epilogue's stores
