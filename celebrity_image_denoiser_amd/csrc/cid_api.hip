@@ -162,7 +162,7 @@ void pack_winograd_u(const LayerDef& L, const float* w, float* dst) {
 
 // Winograd F(4x2,3x3) filter transform U = G2 g G4^T — rows by the F(2,3) matrix of pack_winograd_u, columns by F(4,3) at the
 // points 0, 3/4, -3/4, 3/2, -3/2, inf (24 values per (co, ci)) —, in double, rounded once to fp32, laid out for k_wino42_conv:
-//   [nb = co/64][unit][a][q = 6*e2 + b][lane = 16*g + j][cg],   ci = 16*(unit/2) + 4*g + 2*((unit%2) ^ (g&1)) + e2,  co = 64*nb + 16*cg + j
+//   [nb = co/64][unit][a][q = 6*e2 + b][lane = 16*g + j][cg],   ci = 16*(unit/2) + 4*g + 2*((unit%2) ^ (g&1)) + e2,  co = 64*nb + 4*j + cg
 // (one 16-byte quad per lane = the four channel groups of position (a, b) at k-step e2: one V value, four MFMAs)
 void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
     static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -179,7 +179,7 @@ void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
             double tmp[4][3];
             for (int a = 0; a < 4; ++a)
                 for (int q = 0; q < 3; ++q) tmp[a][q] = G2[a][0] * g[0 * 3 + q] + G2[a][1] * g[1 * 3 + q] + G2[a][2] * g[2 * 3 + q];
-            const int nb = co >> 6, cg = (co >> 4) & 3, j = co & 15;
+            const int nb = co >> 6, j = (co >> 2) & 15, cg = co & 3;   // column j of channel group cg = channel 4j + cg: see the kernel's epilogue
             // lane group gg reads the 8-byte half (ci >> 1) & 1 of its LDS quad for unit s2 = half ^ (gg & 1): odd channel groups take
             // the halves in the other order, which makes the kernel's ds_read_b64 conflict-free (wino42_kernels.h, xbase / ybase)
             const int ck = ci >> 4, gg = (ci >> 2) & 3, s2 = ((ci >> 1) & 1) ^ (gg & 1), e2 = ci & 1;

@@ -30,7 +30,10 @@
 //   * B (U quads: the four channel groups of one (b, k-step)) straight from L2 into a ring of six quads, refilled right after use.
 //   * epilogue: column transform in registers (6 -> 4); the row transform (4 -> 2) needs all four waves' rows: wave w takes the
 //     tile quarter r = w (tiles 4g + w, all 64 channels), the other three rows come through LDS (48 KiB, one pass); bias, ReLU,
-//     optional 2x2 max-pool, whole 256-byte pixels through wave-private staging.
+//     optional 2x2 max-pool.  (r3) MFMA column j of channel group cg is output channel 4j + cg, so a lane's four groups are four
+//     consecutive channels and its results leave as 16-byte quads straight from registers (sixteen lanes = one pixel's 256 bytes):
+//     the transposing pass through LDS of rounds 1-2 (32 ds_write_b32 + 8 ds_read_b128 per lane and item) and the epilogue's third
+//     barrier are gone (the ZOUT variant still stages: its contraction reads the pixels as MFMA operands).
 //   * (r3) a workgroup WALKS tiles: work item id = blockIdx.x, + gridDim.x, ... (cid_api.hip launches about two workgroups per CU
 //     when there are more items than that).  Chunk 0 of a tile lives in a third LDS buffer X that the exchange / staging area of
 //     the epilogue does not touch, so the NEXT tile's chunk 0 is fetched under the current tile's last chunk (its DMA offsets are
@@ -436,9 +439,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     const int lane = lane_e, m16 = lane_e & 15, g = lane_e >> 4;
     // Wave w finishes tile quarter r = w: the tiles 4g + w (g = lane >> 4) for all four channel groups.  Its bias values are
     // requested here; the column transform and the exchange cover their latency.
-    float bias_v[4];
-#pragma unroll
-    for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[nb * WN2 + cg * 16 + m16];
+    // MFMA column j = m16 of channel group cg is output channel 64 nb + 4 m16 + cg (pack_winograd42_u): a lane's four groups are four
+    // CONSECUTIVE channels, so its results leave as 16-byte quads straight from registers — no transposing pass through LDS
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + nb * WN2 + 4 * m16);
     if (has_next) load_slot_entries();   // for the offsets formed at the tile boundary; older than the epilogue's stores, so its wait skips them
     // step 1, in registers: mp[cg][r] = (b' = 0..3) = sum_b A4^T[b'][b] acc[b][cg][r]
     f32x4 mp[4][4];
@@ -497,25 +500,26 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 Y[cg][1][e] = m[1][e] - (m[2][e] + m[3][e]);
             }
         }
-        __syncthreads();                                     // exchange area is dead: wave-private store staging
-        // step 3: lane (channel m16 of every group cg, quarter g) holds the 2x4 pixels of tile 4g + W.  Staged as
-        // [quarter g][pixel a'*4 + b'][64 channels] (68-float rows, 16 floats between quarters: conflict-free writes), read back
-        // as 16-byte channel quads: sixteen lanes write one pixel's 256 bytes.
-        constexpr int STR = 68, QSTR = 8 * STR + 16;
-        float* stg = reinterpret_cast<float*>(ldsw) + W * (4 * QSTR);
-        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        // step 3: lane (m16, quarter g) holds pixels (a', b') of tile 4g + W for the four consecutive channels 4 m16 + cg.
         const int cbase = nb * WN2;
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg)
+        const int tile_l = 4 * g + W, ttr_l = tile_l / TC, ttc_l = tile_l - ttr_l * TC;       // this lane's tile inside the workgroup's block
+        auto quad = [&](int ap, int bp) {                                                    // bias + ReLU of pixel (a', b'), channels 4 m16 .. + 3
+            return f32x4{fmaxf(Y[0][ap][bp] + bias4[0], 0.f), fmaxf(Y[1][ap][bp] + bias4[1], 0.f), fmaxf(Y[2][ap][bp] + bias4[2], 0.f),
+                         fmaxf(Y[3][ap][bp] + bias4[3], 0.f)};
+        };
+        if constexpr (ZOUT) {
+            // upconv1[0] as the producer of the last layer's input (see k_wino64_conv): relu(y) of the wave's 32 pixels x 64 channels is
+            // staged [quarter g][pixel a'*4 + b'][64 channels] (68-float rows, 16 floats between quarters; one 16-byte write per pixel:
+            // sixteen lanes write one pixel's 256 bytes); z[p][3*tap + co] = sum_ci relu(y)[p][ci] * W2[co][ci][tap] is a [32 x 64] x
+            // [64 x 32 (27 used)] product, 32 MFMAs of 32x32x2, stored as 27 planes [N, 27, H, W].  MFMA row i = pixel (quarter i >> 3, i & 7).
+            __syncthreads();                                 // exchange area is dead: wave-private staging
+            constexpr int STR = 68, QSTR = 8 * STR + 16;
+            float* stg = reinterpret_cast<float*>(ldsw) + W * (4 * QSTR);
 #pragma unroll
             for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
-                for (int bp = 0; bp < 4; ++bp) stg[g * QSTR + (ap * 4 + bp) * STR + cg * 16 + m16] = fmaxf(Y[cg][ap][bp] + bias_v[cg], 0.f);
-        wave_lds_fence();
-        if constexpr (ZOUT) {
-            // upconv1[0] as the producer of the last layer's input (see k_wino64_conv): the wave's staging holds relu(y) of its 32
-            // pixels x 64 channels; z[p][3*tap + co] = sum_ci relu(y)[p][ci] * W2[co][ci][tap] is a [32 x 64] x [64 x 32 (27 used)]
-            // product, 32 MFMAs of 32x32x2, stored as 27 planes [N, 27, H, W].  MFMA row i = pixel (quarter i >> 3, i & 7).
+                for (int bp = 0; bp < 4; ++bp) *reinterpret_cast<f32x4*>(stg + g * QSTR + (ap * 4 + bp) * STR + 4 * m16) = quad(ap, bp);
+            wave_lds_fence();
             const int i32 = lane & 31, h = lane >> 5;
             f32x4 zb[2][4];
 #pragma unroll
@@ -541,62 +545,49 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                 }
             // lane (column j = i32, half h) holds z[pixel (r&3) + 8*(r>>2) + 4*h][j]: registers 4q..4q+3 are the four pixels b' = 0..3
             // of row a' = h of tile 4q + W — one 16-byte store each into plane j
-            {
-                const __amdgpu_buffer_rsrc_t rz = out_rsrc(a.zout, (size_t)n * 27 * a.Hs * a.Ws, 27 * a.Hs * a.Ws);
-                const unsigned lane_off = (unsigned)(((i32 * a.Hs + h) * a.Ws) * 4);       // plane i32, row offset h
+            const __amdgpu_buffer_rsrc_t rz = out_rsrc(a.zout, (size_t)n * 27 * a.Hs * a.Ws, 27 * a.Hs * a.Ws);
+            const unsigned zlane = (unsigned)(((i32 * a.Hs + h) * a.Ws) * 4);              // plane i32, row offset h
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;          // compile-time
-                    const int yb = y0 + 2 * ttr, xx = x0 + 4 * ttc;                             // scalar
-                    const unsigned soff = xx < a.Ws ? (unsigned)((yb * a.Ws + xx) * 4) : 0x7ffffff0u;
-                    const unsigned vo = (i32 < 27 && yb + h < a.Hs) ? lane_off : 0x7ffffff0u;
-                    store16(f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]}, rz, vo, soff);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;          // compile-time
+                const int yb = y0 + 2 * ttr, xx = x0 + 4 * ttc;                             // scalar
+                const unsigned soff = xx < a.Ws ? (unsigned)((yb * a.Ws + xx) * 4) : 0x7ffffff0u;
+                const unsigned vo = (i32 < 27 && yb + h < a.Hs) ? zlane : 0x7ffffff0u;
+                store16(f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]}, rz, vo, soff);
             }
             return;
         }
-        {   // pass `it`: pixels (it & 1) * 4 + l4 of tile quarter it >> 1 (l4 = lane >> 4: the column inside the tile) x 16 channel quads
-            const int l4 = lane >> 4, q16 = lane & 15;
-            const float* rd = stg + l4 * STR + 4 * q16;
+        // Stores straight from registers (no third barrier, no staging): one per-lane offset per item — the lane's tile and channel
+        // quad — plus a scalar offset per pixel (a', b'); a wave instruction writes four pixels' 256 bytes.
+        {
+            const bool full = y0 + 2 * TRW <= a.Hs && x0 + 4 * TC <= a.Ws;                    // workgroup-uniform: no ragged edge in this block
+            const int yl = 2 * ttr_l, xl = 4 * ttc_l;
             const __amdgpu_buffer_rsrc_t ro = out_rsrc(a.out, (size_t)n * a.Hs * a.Ws * a.out_ps, a.Hs * a.Ws * a.out_ps);
-            const unsigned lane_off = (unsigned)((l4 * a.out_ps + a.out_coff + cbase + 4 * q16) * 4);
+            const unsigned lane_off = (unsigned)((__umul24((unsigned)(__umul24((unsigned)yl, (unsigned)a.Ws) + xl), (unsigned)a.out_ps) + a.out_coff + cbase + 4 * m16) * 4);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int qt = it >> 1, hi = it & 1, tile = 4 * qt + W, ttr = tile / TC, ttc = tile - ttr * TC;   // compile-time
-                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + qt * QSTR + hi * 4 * STR);
-                const int yy = y0 + 2 * ttr + hi, xb = x0 + 4 * ttc;                                             // scalar
-                const unsigned soff = yy < a.Hs ? (unsigned)(((yy * a.Ws + xb) * a.out_ps) * 4) : 0x7ffffff0u;
-                const unsigned vo = xb + l4 < a.Ws ? lane_off : 0x7ffffff0u;
-                store16(v, ro, vo, soff);
-            }
+            for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+                for (int bp = 0; bp < 4; ++bp) {
+                    const unsigned soff = (unsigned)((((y0 + ap) * a.Ws + x0 + bp) * a.out_ps) * 4);      // scalar
+                    const unsigned vo = (full || (y0 + yl + ap < a.Hs && x0 + xl + bp < a.Ws)) ? lane_off : 0x7ffffff0u;
+                    store16(quad(ap, bp), ro, vo, soff);
+                }
         }
         if (POOL) {
-            wave_lds_fence();
+            const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+            const __amdgpu_buffer_rsrc_t rp = out_rsrc(a.pool, (size_t)n * Hp * Wp * COUT, Hp * Wp * COUT);
+            const unsigned plane_off = (unsigned)(((__umul24((unsigned)ttr_l, (unsigned)Wp) + 2 * ttc_l) * COUT + cbase + 4 * m16) * 4);
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg)
+            for (int pb = 0; pb < 2; ++pb) {
+                f32x4 v;
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
+                for (int cg = 0; cg < 4; ++cg) {
                     const float mx = fmaxf(fmaxf(Y[cg][0][2 * pb], Y[cg][0][2 * pb + 1]), fmaxf(Y[cg][1][2 * pb], Y[cg][1][2 * pb + 1]));
-                    stg[g * QSTR + pb * STR + cg * 16 + m16] = fmaxf(mx + bias_v[cg], 0.f);
+                    v[cg] = fmaxf(mx + bias4[cg], 0.f);
                 }
-            wave_lds_fence();
-            {   // 4 quarters x 2 pooled pixels x 16 channel quads: pass `it` covers quarters 2 it + (l4 >> 1), pooled pixel l4 & 1
-                const int l4 = lane >> 4, q16 = lane & 15;
-                const float* rd = stg + (l4 >> 1) * QSTR + (l4 & 1) * STR + 4 * q16;
-                const __amdgpu_buffer_rsrc_t rp = out_rsrc(a.pool, (size_t)n * Hp * Wp * COUT, Hp * Wp * COUT);
-                const int tile0 = 4 * (l4 >> 1) + W, ttr0 = tile0 / TC, ttc0 = tile0 - ttr0 * TC;
-                const int pyl = ttr0, pxl = 2 * ttc0 + (l4 & 1);
-                const unsigned lane_off = (unsigned)(((pyl * Wp + pxl) * COUT + cbase + 4 * q16) * 4);
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(rd + it * 2 * QSTR);
-                    const int dr = TC <= 8 ? it * (8 / TC) : 0, dc = TC <= 8 ? 0 : it * 16;
-                    const int pyb = (y0 >> 1) + dr, pxb = (x0 >> 1) + dc;
-                    const unsigned soff = (unsigned)(((pyb * Wp + pxb) * COUT) * 4);
-                    const unsigned vo = (pyb + pyl < Hp && pxb + pxl < Wp) ? lane_off : 0x7ffffff0u;
-                    store16(v, rp, vo, soff);
-                }
+                const unsigned soff = (unsigned)((((y0 >> 1) * Wp + (x0 >> 1) + pb) * COUT) * 4);        // scalar
+                const unsigned vo = ((y0 >> 1) + ttr_l < Hp && (x0 >> 1) + 2 * ttc_l + pb < Wp) ? plane_off : 0x7ffffff0u;
+                store16(v, rp, vo, soff);
             }
         }
     };
@@ -606,9 +597,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
         case 2: epilogue(std::integral_constant<int, 2>{}); break;
         default: epilogue(std::integral_constant<int, 3>{}); break;
     }
-    // Barrier discipline of the four instantiations above: each executes exactly three __syncthreads() on every path (the ZOUT
-    // `return` leaves the lambda after the third).  s_barrier is not PC-matched, so waves meeting at different program counters
-    // is what the hardware does anyway; what must hold — and does, by construction of the one lambda body — is the equal COUNT.
+    // Barrier discipline of the four instantiations above: each executes the same number of __syncthreads() on every path — two
+    // (three in the ZOUT variant, whose `return` leaves the lambda after the third).  s_barrier is not PC-matched, so waves meeting at
+    // different program counters is what the hardware does anyway; what must hold — and does, by construction of the one lambda
+    // body — is the equal COUNT.
     tr_lap(tr_epi);
     if (!has_next) break;                                     // workgroup-uniform
     __syncthreads();   // every wave has left the exchange / staging area: buffers 0 / 1 may be written again
