@@ -402,6 +402,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     for (;;) {   // ---- one tile per iteration ----
     tile_scalars();
     tr_lap(tr_bnd);
+    // The main loop runs at wave priority 1, epilogue and tile boundary at 0: when the sibling workgroup's wave on this SIMD is in its
+    // epilogue, this wave's MFMA stream goes first and the epilogue's vector instructions take the gaps (same-box +0.85 % on the forward,
+    // -2 % on the CIN = 64 layers and upconv1.0; the opposite assignment +-0: profiles/r03_ab_wino42_walk.txt).  Round 2 had measured
+    // priority 2 OUTSIDE the main loop as a loss.
+    __builtin_amdgcn_s_setprio(1);
     chunk(T{}, T{}, T{}, F{}, 0);
     chunk(F{}, T{}, std::integral_constant<bool, (NCHUNK > 3)>{}, T{}, 1);
     for (int ck = 2; ck + 2 < NCHUNK; ck += 2) {
@@ -413,6 +418,7 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
 
     tr_lap(tr_main);
     ++tr_tiles;
+    __builtin_amdgcn_s_setprio(0);
 #ifdef CID_W42_ASM_MFMA
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");   // MFMA write -> VALU read of the accumulators (up to 18 wait states for an 8-pass MFMA)
 #endif
