@@ -39,8 +39,8 @@ const char* kKernelNames[NL] = {
 
 const char* kHalfKernelNames[NL] = {
     "k_conv_head_h16", "k_conv3x3_h16<64, 64, 1>", "k_conv3x3_h16<64, 128, 0>", "k_conv3x3_h16<128, 128, 1>",
-    "k_conv3x3_h16<128, 256, 0>", "k_conv3x3_h16<256, 256, 0>", "k_convt_h<256, 128>", "k_conv3x3_h16<256, 128, 0>",
-    "k_conv3x3_h16<128, 128, 0>", "k_convt_h<128, 64>", "k_conv3x3_h16<128, 64, 0>", "k_conv_tail_h",
+    "k_conv3x3_h16<128, 256, 0>", "k_conv3x3_h16<256, 256, 0>", "k_convt_t16<256, 128>", "k_conv3x3_h16<256, 128, 0>",
+    "k_conv3x3_h16<128, 128, 0>", "k_convt_t16<128, 64>", "k_conv3x3_h16<128, 64, 0>", "k_conv_tail_h",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -192,14 +192,14 @@ void pack_winograd42_u(const LayerDef& L, const float* w, float* dst) {
         }
 }
 
-// k_convt_h: [nb][chunk][k-step][ns][lane = 32*h + j][8] halfs with ci = 32*chunk + 16*kstep + 8*h + e and column
-// n' = (kh*2 + kw)*COUT + co = 64*nb + 32*ns + j — lane (h, j) of v_mfma_f32_32x32x16_f16 holds B[k = 8h..8h+7][col = j].
-size_t packed_index_h(const LayerDef& L, int co, int ci, int kh, int kw) {
-    const int np = (kh * 2 + kw) * L.cout + co;
-    const int nb = np >> 6, ns = (np >> 5) & 1, j = np & 31;
-    const int ck = ci >> 5, ks = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
-    const int nchunk = L.cin / 32;
-    return ((((size_t)(nb * nchunk + ck) * 2 + ks) * 2 + ns) * 64 + h * 32 + j) * 8 + e;
+// k_convt_t16: [tap][cb][k-step][mt][lane = 16*kga + row][8] halfs — the A operand of v_mfma_f32_16x16x32_f16: A[row][k = 8 kga + e] with
+// ci = 32*kstep + 8*kga + e and row `row` of M tile `mt` = channel 64 cb + 32 (mt >> 1) + 8 (row >> 2) + 4 (mt & 1) + (row & 3).
+size_t packed_index_ht(const LayerDef& L, int co, int ci, int kh, int kw) {
+    const int tap = kh * 2 + kw, cb = co >> 6, c = co & 63;
+    const int mt = ((c >> 5) << 1) | ((c >> 2) & 1), row = (((c >> 3) & 3) << 2) | (c & 3);
+    const int ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
+    const int CB = L.cout / 64, KS = L.cin / 32;
+    return (((((size_t)(tap * CB + cb) * KS + ks) * 4 + mt) * 64) + kga * 16 + row) * 8 + e;
 }
 
 // k_conv3x3_h16: [nb][32-ch chunk][dx][dy][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
@@ -516,8 +516,14 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     a.walk = 0;
-    if constexpr (MODE == 2) hipLaunchKernelGGL((k_convt_h<CIN, COUT>), dim3(8 * g.per_xcd * NB), dim3(THREADS), 0, s, a);
-    else {
+    if constexpr (MODE == 2) {
+        // streaming form: persistent workgroups (two waves per SIMD: 2 per CU of four waves, 1 of eight) over runs of TP input pixels
+        using CG = ConvTGeom<CIN, COUT>;
+        a.tiles_x = (Hin * Win + CG::TP - 1) / CG::TP; a.tiles_total = N * a.tiles_x;
+        a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(Win);
+        const int wgs = device_cus() * 2 / CG::CB;
+        hipLaunchKernelGGL((k_convt_t16<CIN, COUT>), dim3(a.tiles_total < wgs ? a.tiles_total : wgs), dim3(64 * CG::NW), 0, s, a);
+    } else {
         // walking workgroups (conv_kernels_f16.h): three per CU (47 KiB of LDS, <= 168 VGPRs) once there are more items than that —
         // on the layers with CIN <= 128, where an item is short beside its prologue (same-box: down1.2 -15 %, down2.0 -11 %, the
         // CIN = 128 layers -0.3...-1.5 %).  With CIN = 256 walking LOSES 3-5 %: a tile's NB column blocks then run one after the
@@ -690,7 +696,7 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
-                hd[L.kind == CONV ? packed_index_h16(L, co, ci, kh, kw) : packed_index_h(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
+                hd[L.kind == CONV ? packed_index_h16(L, co, ci, kh, kw) : packed_index_ht(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
         }
         if (L.kind == HEAD) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = co % 16, kg) of group co / 16 holds k = 8kg..8kg+7

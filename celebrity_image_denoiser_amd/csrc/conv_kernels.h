@@ -129,32 +129,6 @@ __device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixF
     wave_lds_fence();
 }
 
-// Same slab, rounded to IEEE half on the way out: 8 channels (16 bytes) per lane, 8 lanes per pixel, 8 pixels
-// per instruction.  Used by the fp16-storage path (conv_kernels_f16.h) and by the head when it feeds that path.
-template <int NPIX, typename ValFn, typename PixFn, typename PtrFn>
-__device__ __forceinline__ void wide_store_h(float* stg, int lane, ValFn val, PixFn pix, PtrFn ptr) {
-    const int i = lane & 31;
-#pragma unroll
-    for (int k = 0; k < NPIX / 2; ++k) {
-        const int px = pix(k);
-        stg[px * WS_STRIDE + i] = val(0, k);
-        stg[px * WS_STRIDE + 32 + i] = val(1, k);
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int it = 0; it < NPIX / 8; ++it) {
-        const int px = it * 8 + (lane >> 3);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
-        f16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
-        _Float16* g = ptr(px);
-        if (g) *reinterpret_cast<f16x8*>(g + (lane & 7) * 8) = v;
-    }
-    wave_lds_fence();
-}
-
 // Interior-tile variants: the slab's pixels are `stride` floats (halfs) apart starting at the wave-uniform `base`, all in
 // range.  One per-lane offset for the whole tail, the rest is scalar: no per-pixel pointer or bounds arithmetic.
 template <int NPIX, int WSF = WS_STRIDE, typename ValFn, typename PixFn>
@@ -172,29 +146,6 @@ __device__ __forceinline__ void wide_store_full(float* stg, int lane, ValFn val,
     for (int it = 0; it < NPIX / 4; ++it) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * WSF + (lane & 15) * 4);
         *reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off) = v;
-    }
-    wave_lds_fence();
-}
-template <int NPIX, typename ValFn, typename PixFn>
-__device__ __forceinline__ void wide_store_h_full(float* stg, int lane, ValFn val, PixFn pix, _Float16* base, int stride) {
-    const int i = lane & 31;
-#pragma unroll
-    for (int k = 0; k < NPIX / 2; ++k) {
-        const int px = pix(k);
-        stg[px * WS_STRIDE + i] = val(0, k);
-        stg[px * WS_STRIDE + 32 + i] = val(1, k);
-    }
-    wave_lds_fence();
-    const int lane_off = (lane >> 3) * stride + (lane & 7) * 8;
-#pragma unroll
-    for (int it = 0; it < NPIX / 8; ++it) {
-        const int px = it * 8 + (lane >> 3);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
-        f16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
-        *reinterpret_cast<f16x8*>(base + (size_t)(it * 8) * stride + lane_off) = v;
     }
     wave_lds_fence();
 }

@@ -7,7 +7,7 @@
 //
 //   k_conv_head_h16   down1[0]                       v_mfma_f32_16x16x32_f16, K = 27 -> one step
 //   k_conv3x3_h16     the eight 3x3 layers           v_mfma_f32_16x16x32_f16, 32-channel chunks, B by LDS-DMA
-//   k_convt_h         up2, up1                       v_mfma_f32_32x32x16_f16
+//   k_convt_t16       up2, up1                       v_mfma_f32_16x16x32_f16 (streaming: weights in registers, pixels by LDS-DMA)
 //   k_conv_tail_h     upconv1[2] + tanh              v_mfma_f32_32x32x16_f16 (z = x . W per halo pixel, then nine shifted sums)
 //
 // The forward of this path runs at the board's power limit: the 16x16x32 shape moves half the accumulator
@@ -34,140 +34,163 @@ struct GemmConvArgsH {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Transposed convolutions of the fp16-storage path: up2 / up1 = ConvTranspose2d(C, C/2, 2, stride=2) (app.py:63,71), each tap a
-// 1x1 GEMM whose 8x32 input pixels scatter to every other pixel of two output rows.  Workgroup = 256 input pixels x 64 of the
-// 4*COUT columns (one tap, 64 channels), wave = 64 pixels x 64 columns as 2x2 tiles of v_mfma_f32_32x32x16_f16:
-//   * K = 32-channel chunks x two 16-channel k-steps; A: pixel = 64 B of data + 16 B pad in LDS (consecutive pixels conflict-free
-//     for ds_read_b128), fetched global -> registers -> LDS one piece per k-step under the MFMAs; B: two 1 KiB quads per k-step
-//     straight from L2 (pre-packed per lane, packed_index_h), one k-step ahead;
-//   * epilogue: bias on the fp32 accumulators (no activation: app.py:87,94), one rounding to half, 16-byte stores through the LDS
-//     staging of wide_store_h into the concat buffer's first half.
+// k_convt_t16 — the transposed convolutions of the fp16-storage path: up2 / up1 = ConvTranspose2d(C, C/2, 2, stride=2) (app.py:65,73)
+// as a STREAMING kernel (round 3).  At fp16 a 2x2 stride-2 ConvT is bound by HBM (171 FLOP/B at CIN = 256, 85 at CIN = 128, against a
+// ridge of 312): every input pixel is read once and four output pixels are written, with no halo.  Rounds 1-2's k_convt_h (git history)
+// reached 0.35 / 0.55 of that roofline: one workgroup per (tile, tap, 64 channels) re-read the input tile per tap, streamed its weights
+// from L2 per tile and went through two barriers per 32-channel chunk.  Here (0.69 / 0.68, profiles/r03_ab_f16_convt.txt):
+//   * wave = (tap, 64-channel block): its CIN x 64 weights stay in REGISTERS for the life of the workgroup (64 VGPRs at CIN = 128,
+//     128 at CIN = 256) as the A operands of v_mfma_f32_16x16x32_f16 — channels are the MFMA ROWS, pixels the columns;
+//   * workgroups are persistent and walk tiles of 32 KiB of input pixels (TP consecutive pixels of one image, all CIN channels:
+//     one contiguous run of memory), brought in by LDS-DMA into one of two buffers while the other is computed on: ONE barrier per tile;
+//   * LDS holds a pixel's 16-byte slots XOR-swizzled with the pixel index (phys = s ^ (p & 15)), applied on the SOURCE side of the DMA
+//     (lane L always lands at L * 16): the pixel operand is read with conflict-free ds_read_b128 although pixels are 256 / 512 B apart;
+//   * row m = 4 kg + r of M tile mt is channel 32 (mt >> 1) + 8 kg + 4 (mt & 1) + r (packed_index_ht): a lane's two M tiles of a pair
+//     are 8 CONSECUTIVE channels of one pixel, so results leave as 16-byte stores straight from the accumulators (four lanes = 64
+//     contiguous bytes of a pixel), no staging.
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(THREADS, 2) k_convt_h(const GemmConvArgsH a) {
-    constexpr int LW = TILE_W, LPIX = TILE_W * TILE_H;
-    constexpr int NSLOT = LPIX * 4;                  // 16-byte data slots (8 halfs) per chunk tile
-    constexpr int NLOAD = NSLOT / THREADS;           // 4
-    constexpr int NCHUNK = CIN / KCHUNK;             // 32-channel chunks
-    constexpr int NOUT = 4 * COUT;
-    constexpr int NB = NOUT / NTILE, CB = COUT / NTILE;
-    constexpr int SPC = 2;                           // k-steps (16 channels each) per chunk
-    static_assert(CIN % KCHUNK == 0 && COUT % NTILE == 0 && NSLOT % THREADS == 0, "layer dims");
-    constexpr int LDS_SLOTS = (LPIX * HPS * 16 > 4 * WS_FLOATS * 4) ? LPIX * HPS : (4 * WS_FLOATS * 4 + 15) / 16;
-    __shared__ f32x4 lds[LDS_SLOTS];                 // input tile (half); later the fp32 store staging
+struct ConvTGeom {
+    static constexpr int CB = COUT / 64;            // 64-channel blocks
+    static constexpr int NW = 4 * CB;               // waves per workgroup: (tap, block)
+    static constexpr int S = CIN / 8;               // 16-byte slots per pixel
+    static constexpr int TP = 2048 / S;             // pixels per tile (32 KiB of input)
+    static constexpr int TN = TP / 16;              // 16-pixel MFMA column tiles
+    static constexpr int KS = CIN / 32;             // k-steps
+    static constexpr int ROUNDS = TP * S / (NW * 64);   // DMA instructions per wave and tile; 16 pixels per round
+    static constexpr int BUFQ = TP * S;             // quads per buffer
+    static_assert(COUT % 64 == 0 && CIN % 32 == 0 && (S == 16 || S == 32), "layer dims");
+    static_assert(NW * 64 / S == 16, "a DMA round covers 16 pixels: the swizzle term (p & 15) is the same in every round");
+};
 
-    int mt, nb;
-    if (!decode_block(a.tiles_total, a.tiles_per_xcd, NB, mt, nb)) return;
-    int n, ty, tx;
-    decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
-    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
-    const int tap2 = nb / CB, cobase = (nb - tap2 * CB) * NTILE;
-    float bias_v[2];
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns) bias_v[ns] = a.bias[cobase + ns * 32 + i];
+// GemmConvArgsH as k_convt_t16 reads it: tiles_x = tiles per image, tiles_total = N * tiles_x, rcp_x = tile_rcp(tiles_x),
+// rcp_xy = tile_rcp(Win); Hin x Win = the input image (pixel stride in_ps halfs), Hc x Wc = the part of it that is computed.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(64 * 4 * (COUT / 64), 2) k_convt_t16(const GemmConvArgsH a) {
+    using G = ConvTGeom<CIN, COUT>;
+    constexpr int S = G::S, TP = G::TP, TN = G::TN, KS = G::KS, NW = G::NW, ROUNDS = G::ROUNDS, BUFQ = G::BUFQ, CB = G::CB, TG = 4;
+    static_assert(TN % TG == 0, "column tiles are processed TG at a time");
+    __shared__ f32x4 lds[2 * BUFQ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tap = wave & 3, cb = wave >> 2, kh = tap >> 1, kw = tap & 1;
+    const int c16 = lane & 15, kg = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= a.tiles_total) return;
+    const int HW = a.Hin * a.Win;
 
-    // this thread's pieces of the input tile: piece `it` is data slot s = it*256 + tid (pixel s/4, slot s%4); raw buffer loads over
-    // this image with fixed per-piece byte offsets and a scalar chunk offset, out-of-image pieces out of range (read as zero)
-    const _Float16* inb = a.in + (size_t)n * a.Hin * a.Win * a.in_ps;
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
-    unsigned goff[NLOAD];
+    // ---- this wave's weights and bias, once ----
+    f16x8 wf[KS][4];
+    {
+        const f16x8* wp = reinterpret_cast<const f16x8*>(a.w) + (size_t)((tap * CB + cb) * KS) * 4 * 64 + lane;
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-        const int s = it * THREADS + tid;
-        const int p = s >> 2, c = s & 3;
-        const int gy = y0 + p / LW, gx = x0 + p % LW;
-        const bool ok = (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-        goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + c * 8) * 2) : 0x7ffffff0u;
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) wf[ks][mt] = wp[(ks * 4 + mt) * 64];
     }
-    const int wslot = (tid >> 2) * HPS + (tid & 3);   // piece `it` lands at wslot + it*64*HPS
-    auto tile_load = [&](int it, int ck) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, goff[it], ck * (KCHUNK * 2), 0));
+    f32x4 bias4[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + 32 * (mt >> 1) + 8 * kg + 4 * (mt & 1));
+
+    // ---- input DMA: lane L of (wave, round j) fills physical quad ((j * NW + wave) * 64 + L) of the buffer ----
+    const int pl0 = (wave * 64 + lane) / S, sp = lane & (S - 1);          // round 0: tile-local pixel, physical slot
+    const unsigned dma_lane = (unsigned)(pl0 * a.in_ps * 2 + ((sp ^ (pl0 & 15)) * 16));
+    auto image_rsrc = [&](int n) {
+        const unsigned long long p = (unsigned long long)(a.in + (size_t)n * HW * a.in_ps);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, HW * a.in_ps * 2, 0x00020000);
+    };
+    auto split = [&](int t, int& n, int& chunk) {                          // tile -> image, run of TP pixels inside it
+        n = a.tiles_x > 1 ? (int)__umulhi((unsigned)t, a.rcp_x) : t;   // at most one too large (see the pixel decode below)
+        chunk = t - n * a.tiles_x;
+        if (chunk < 0) { --n; chunk += a.tiles_x; }
+    };
+    auto dma_tile = [&](int t, int buf) {
+        int n, chunk;
+        split(t, n, chunk);
+        const __amdgpu_buffer_rsrc_t rsrc = image_rsrc(n);
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int q = chunk * TP + j * 16 + pl0;                       // pixel of the image; beyond it: zeros (offset out of range —
+            const unsigned vo = q < HW ? dma_lane : 0x7ffffff0u;           // the scalar offset is not part of the hardware's range check)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)&lds[buf * BUFQ + (j * NW + wave) * 64], 16, vo,
+                                                     (chunk * TP + j * 16) * a.in_ps * 2, 0, 0);
+        }
     };
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][ns][r] = 0.f;
-
-    const int pbase0 = ((2 * wave) * LW + i) * HPS + h;   // slot of (row 2*wave, column i), k-step 0
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * NOUT * 2, 0x00020000);
-    const int wbase = nb * NCHUNK * SPC * 2048, wlane = lane * 16;
-    auto b_load = [&](int gstep, int ns) -> f16x8 {   // step g is the 2 KiB at (nb*NCHUNK*SPC + g)*2048 bytes
-        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wlane, wbase + gstep * 2048 + ns * 1024, 0));
-    };
-
-    f32x4 pre[NLOAD];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pre[it] = tile_load(it, 0);
-    f16x8 bcur[2], bnxt[2];
-    bcur[0] = b_load(0, 0);
-    bcur[1] = b_load(0, 1);
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) lds[wslot + it * 64 * HPS] = pre[it];
-    __syncthreads();
-
+    // ---- pixel operand: lane (c16, kg) reads slot 4 ks + kg of pixel 16 t + c16: physical quad (16 t + c16) * S + ((4 ks + kg) ^ c16) ----
     const f16x8* ldsh = reinterpret_cast<const f16x8*>(lds);
-    auto chunk = [&](auto pref_tag, int ck) {
-        constexpr bool PREF = decltype(pref_tag)::value;
-        f16x8 acur[2], anxt[2];
+    int rd[KS];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acur[m] = ldsh[pbase0 + m * LW * HPS];
-#pragma unroll
-        for (int st = 0; st < SPC; ++st) {
-            if (st + 1 < SPC) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) anxt[m] = ldsh[pbase0 + m * LW * HPS + 2 * (st + 1)];
-            }
-            if (PREF || st + 1 < SPC) {
-                bnxt[0] = b_load(ck * SPC + st + 1, 0);
-                bnxt[1] = b_load(ck * SPC + st + 1, 1);
-            }
-            if (PREF) {
-#pragma unroll
-                for (int it = st * (NLOAD / SPC); it < (st + 1) * (NLOAD / SPC); ++it) pre[it] = tile_load(it, ck + 1);
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns)
-                    acc[m][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[m], bcur[ns], acc[m][ns], 0, 0, 0);
-            if (st + 1 < SPC) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acur[m] = anxt[m];
-            }
-            if (PREF || st + 1 < SPC) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
-        }
-        if (PREF) {
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < NLOAD; ++it) lds[wslot + it * 64 * HPS] = pre[it];
-            __syncthreads();
-        }
-    };
-    for (int ck = 0; ck + 1 < NCHUNK; ++ck) chunk(std::true_type{}, ck);
-    chunk(std::false_type{}, NCHUNK - 1);
+    for (int ks = 0; ks < KS; ++ks) rd[ks] = c16 * S + ((4 * ks + kg) ^ c16);
 
-    // ---- epilogue: tap (kh, kw) of input pixel (y, x) is output pixel (2y + kh, 2x + kw) ----
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(lds) + wave * WS_FLOATS;
-    auto xo = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; };
-    const int kh = tap2 >> 1, kw = tap2 & 1;
+    // ---- output: per image a buffer over [2 Hc][2 Wc] pixels of out_ps halfs ----
     const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+    auto out_rsrc = [&](int n) {
+        const unsigned long long p = (unsigned long long)(a.out + (size_t)n * Ho * Wo * a.out_ps);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, Ho * Wo * a.out_ps * 2, 0x00020000);
+    };
+    const unsigned lane_chan = (unsigned)((a.out_coff + cb * 64 + 8 * kg) * 2);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    dma_tile(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < a.tiles_total;                         // workgroup-uniform
+        if (has_next) dma_tile(next, buf ^ 1);                              // lands under this tile's MFMAs and stores
+
+        int n, chunk;
+        split(tile, n, chunk);
+        const __amdgpu_buffer_rsrc_t ro = out_rsrc(n);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int y = y0 + 2 * wave + m;
-        _Float16* orow = a.out + ((size_t)(n * Ho + 2 * y + kh) * Wo + kw) * a.out_ps + a.out_coff + cobase;
-        const int step = 2 * a.out_ps;
-        const bool rowok = y < a.Hc;
-        auto val = [&](int ns, int k) { return acc[m][ns][k] + bias_v[ns]; };
-        if (y0 + TILE_H <= a.Hc && x0 + TILE_W <= a.Wc)
-            wide_store_h_full<32>(stg, lane, val, xo, orow + (size_t)x0 * step, step);
-        else
-            wide_store_h<32>(stg, lane, val, xo,
-                             [&](int px) -> _Float16* { return (rowok && x0 + px < a.Wc) ? orow + (size_t)(x0 + px) * step : nullptr; });
+        for (int t0 = 0; t0 < TN; t0 += TG) {   // TG column tiles at a time: 16 TG accumulator registers beside the resident weights
+            f32x4 acc[TG][4];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const f16x8 px = ldsh[buf * BUFQ + (t0 + t) * 16 * S + rd[ks]];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        if (ks == 0) {
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][mt], px, zero, 0, 0, 0);
+                        } else {
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][mt], px, acc[t][mt], 0, 0, 0);
+                        }
+                    }
+                }
+            // ---- bias (no activation: app.py:89,96), one rounding to half, tap (kh, kw) of pixel (y, x) -> output pixel (2y + kh, 2x + kw) ----
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const unsigned q = (unsigned)(chunk * TP + (t0 + t) * 16 + c16);
+                unsigned y = __umulhi(q, a.rcp_xy);                         // q / Win, at most one too large (q * (rcp * Win - 2^32) < 2^32 * Win)
+                int x = (int)(q - y * (unsigned)a.Win);
+                if (a.Win == 1) { y = q; x = 0; }
+                if (x < 0) { --y; x += a.Win; }
+                const bool ok = (int)q < HW && (int)y < a.Hc && x < a.Wc;
+                const unsigned po = ((2 * y + kh) * (unsigned)Wo + 2 * x + kw) * (unsigned)a.out_ps * 2 + lane_chan;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f16x8 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = (_Float16)(acc[t][2 * hf][r] + bias4[2 * hf][r]);
+                        v[4 + r] = (_Float16)(acc[t][2 * hf + 1][r] + bias4[2 * hf + 1][r]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, ok ? po + hf * 64 : 0x7ffffff0u, 0, 0);
+                }
+            }
+        }
+        if (!has_next) break;
+        // this wave's DMA of the next tile was issued before the 2 TN stores above: all but those have completed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");
+        __syncthreads();   // every wave's part of the next tile has landed, and every wave has left this tile's buffer
+        tile = next;
+        buf ^= 1;
     }
 }
 
