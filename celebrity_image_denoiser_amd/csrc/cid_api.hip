@@ -34,7 +34,7 @@ const LayerDef kLayers[NL] = {
 const char* kKernelNames[NL] = {
     "k_conv_head", "k_gemm_conv<64, 64, 1,", "k_gemm_conv<64, 128, 0,", "k_gemm_conv<128, 128, 1,",
     "k_gemm_conv<128, 256, 0,", "k_gemm_conv<256, 256, 0,", "k_gemm_conv<256, 128, 2,", "k_gemm_conv<256, 128, 0,",
-    "k_gemm_conv<128, 128, 0,", "k_gemm_conv<128, 64, 2,", "k_gemm_conv<128, 64, 0,", "k_conv_tail",
+    "k_gemm_conv<128, 128, 0,", "k_convt_s32<128, 64>", "k_gemm_conv<128, 64, 0,", "k_conv_tail",
 };
 
 const char* kHalfKernelNames[NL] = {
@@ -119,8 +119,13 @@ size_t packed_index(const LayerDef& L, int co, int ci, int kh, int kw) {
             const int col = (kh * 3 + kw) * 3 + co, ck = ci >> 5, g = (ci >> 3) & 3, h = (ci >> 2) & 1, e = ci & 3;
             return (size_t)((ck * 4 + g) * 64 + h * 32 + col) * 4 + e;
         }
-        case CONV:
-        case CONVT: {
+        case CONVT:
+            if (L.cin == 128) {   // up1, k_convt_s32: [tap][g][j][mt][lane = 16*kga + row] — A[row][k = kga] of v_mfma_f32_16x16x4_f32 for k-step j
+                const int g = ci >> 4, kga = (ci >> 2) & 3, j = ci & 3, mt = co >> 4, row = co & 15;   // of group g: ci = 16 g + 4 kga + j, co = 16 mt + row
+                return (((((size_t)(kh * 2 + kw) * (L.cin / 16) + g) * 4 + j) * 4 + mt) * 64) + kga * 16 + row;
+            }
+            [[fallthrough]];
+        case CONV: {
             const int taps = L.kind == CONV ? 9 : 1;
             const int tap = L.kind == CONV ? kh * 3 + kw : 0;
             const int np = L.kind == CONV ? co : (kh * 2 + kw) * L.cout + co;
@@ -475,7 +480,19 @@ hipError_t launch_layer(cid_handle_t h, hipStream_t s, const float* blob, int la
                         float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
     if (h->dtype == CID_DTYPE_F16)
         return launch_gemm_h<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
-    if constexpr (MODE == 2)
+    if constexpr (MODE == 2 && CIN == 128) {   // up1: streaming form, persistent workgroups (two per CU) over runs of TP input pixels
+        using CG = ConvTGeom32<CIN, COUT>;
+        GemmConvArgs a;
+        a.in = in; a.w = blob + kBlob.w_off[layer]; a.bias = blob + kBlob.b_off[layer];
+        a.out = out; a.pool = nullptr;
+        a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps;
+        a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
+        a.tiles_x = (Hin * Win + CG::TP - 1) / CG::TP; a.tiles_y = 1; a.tiles_total = N * a.tiles_x; a.tiles_per_xcd = 0;
+        a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(Win);
+        const int wgs = device_cus() * 2;
+        hipLaunchKernelGGL((k_convt_s32<CIN, COUT>), dim3(a.tiles_total < wgs ? a.tiles_total : wgs), dim3(THREADS), 0, s, a);
+        return hipGetLastError();
+    } else if constexpr (MODE == 2)
         return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
     else
         return launch_conv3x3<CIN, COUT, MODE>(h->algo, s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);

@@ -1080,4 +1080,185 @@ __global__ void __launch_bounds__(THREADS) k_conv_tail_z(const TailZArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_convt_s32 — up1 = ConvTranspose2d(128, 64, 2, stride=2) (app.py:73,96) as a streaming kernel (round 3; the fp16 path's k_convt_t16
+// is the same design, conv_kernels_f16.h).  A 2x2 stride-2 transposed convolution has no halo: every input pixel is read once and
+// produces four output pixels.  k_gemm_conv MODE 2 ran it at 0.75 of the fp32 MFMA peak: one workgroup per (8x32 tile, tap), weights
+// streamed from L2 per k-step, the input tile staged chunk by chunk behind barriers, a prologue and a staged epilogue per 256 MFMAs.  Here:
+//   * wave = tap: its CIN x 64 weights stay in REGISTERS for the life of the workgroup (CIN VGPRs) as the A operands of
+//     v_mfma_f32_16x16x4_f32 — channels are the MFMA rows, pixels the columns;
+//   * persistent workgroups (two per CU) walk tiles of TP consecutive pixels of one image (32 KiB, one contiguous run of memory) brought
+//     in by LDS-DMA into one of two buffers while the other is computed on: one barrier per tile;
+//   * a pixel's 16-byte slots lie XOR-swizzled with the pixel index in LDS (phys = s ^ (p & 15)), applied on the source side of the DMA:
+//     the pixel operand is read with conflict-free ds_read_b128 (one quad = the B values of four consecutive MFMAs) although pixels are
+//     512 B apart;
+//   * row 4 kg + r of M tile mt is channel 16 mt + 4 kg + r: a lane's four accumulator values are four consecutive channels and leave
+//     as 16-byte stores straight from registers (four lanes = 64 contiguous bytes of a pixel), no staging.
+// GemmConvArgs as this kernel reads it: tiles_x = tiles per image, tiles_total = N * tiles_x, rcp_x = tile_rcp(tiles_x),
+// rcp_xy = tile_rcp(Win); Hin x Win = the input image (pixel stride in_ps floats), Hc x Wc = the part of it that is computed.
+template <int CIN, int COUT>
+struct ConvTGeom32 {
+    static constexpr int NW = 4;                    // waves per workgroup = taps
+    static constexpr int S = CIN / 4;               // 16-byte slots per pixel
+    static constexpr int TP = 2048 / S;             // pixels per tile (32 KiB of input)
+    static constexpr int TN = TP / 16;              // 16-pixel MFMA column tiles
+    static constexpr int G = CIN / 16;              // 16-channel groups: one quad per lane = four k-steps
+    static constexpr int PPR = NW * 64 / S;         // pixels per DMA round
+    static constexpr int ROUNDS = TP / PPR;
+    static constexpr int BUFQ = TP * S;             // quads per buffer
+    static_assert(COUT == 64 && CIN == 128, "weights of one tap x 64 channels in CIN registers: up1");
+    static_assert(16 % PPR == 0 && S >= 16, "the swizzle term (p & 15) repeats every 16 / PPR rounds");
+};
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(THREADS, 2) k_convt_s32(const GemmConvArgs a) {
+    using Gm = ConvTGeom32<CIN, COUT>;
+    constexpr int S = Gm::S, TP = Gm::TP, TN = Gm::TN, G = Gm::G, NW = Gm::NW, ROUNDS = Gm::ROUNDS, BUFQ = Gm::BUFQ, PPR = Gm::PPR;
+    constexpr int NV = 16 / PPR;                    // distinct per-lane DMA offsets
+    constexpr int TG = 2;
+    static_assert(TN % TG == 0, "column tiles are processed TG at a time");
+    __shared__ f32x4 lds[2 * BUFQ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tap = wave, kh = tap >> 1, kw = tap & 1;
+    const int c16 = lane & 15, kg = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= a.tiles_total) return;
+    const int HW = a.Hin * a.Win;
+
+    // ---- this wave's weights and bias, once: wf[g][j][mt] = W[ci = 16 g + 4 (lane >> 4) + j][co = 16 mt + (lane & 15)][tap] ----
+    float wf[G][4][4];
+    {
+        const float* wp = a.w + (size_t)tap * G * 16 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) wf[g][j][mt] = wp[((g * 4 + j) * 4 + mt) * 64];
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + 16 * mt + 4 * kg);
+
+    // ---- input DMA: lane L of (wave, round j) fills physical quad ((j * NW + wave) * 64 + L) of the buffer ----
+    const int sp = lane & (S - 1);
+    int pl[NV];
+    unsigned dma_lane[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        pl[v] = ((v * NW + wave) * 64 + lane) / S;                          // tile-local pixel in round v (+ PPR * NV per NV rounds)
+        dma_lane[v] = (unsigned)(pl[v] * a.in_ps * 4 + ((sp ^ (pl[v] & 15)) * 16));
+    }
+    auto image_rsrc = [&](int n) {
+        const unsigned long long p = (unsigned long long)(a.in + (size_t)n * HW * a.in_ps);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, HW * a.in_ps * 4, 0x00020000);
+    };
+    auto split = [&](int t, int& n, int& chunk) {                          // tile -> image, run of TP pixels inside it
+        n = a.tiles_x > 1 ? (int)__umulhi((unsigned)t, a.rcp_x) : t;       // at most one too large (see the pixel decode below)
+        chunk = t - n * a.tiles_x;
+        if (chunk < 0) { --n; chunk += a.tiles_x; }
+    };
+    auto dma_tile = [&](int t, int buf) {
+        int n, chunk;
+        split(t, n, chunk);
+        const __amdgpu_buffer_rsrc_t rsrc = image_rsrc(n);
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int base = chunk * TP + (j / NV) * 16;                   // pixel of the image that round j - j % NV starts at
+            const int q = base + pl[j % NV];                               // beyond the image: zeros (offset out of range — the scalar
+            const unsigned vo = q < HW ? dma_lane[j % NV] : 0x7ffffff0u;   // offset is not part of the hardware's range check)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)&lds[buf * BUFQ + (j * NW + wave) * 64], 16, vo,
+                                                     base * a.in_ps * 4, 0, 0);
+        }
+    };
+
+    // ---- pixel operand: lane (c16, kg) reads slot 4 g + kg of pixel 16 t + c16: physical quad (16 t + c16) * S + ((4 g + kg) ^ c16) ----
+    int rd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) rd[g] = c16 * S + ((4 * g + kg) ^ c16);
+
+    // ---- output: per image a buffer over [2 Hc][2 Wc] pixels of out_ps floats ----
+    const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+    auto out_rsrc = [&](int n) {
+        const unsigned long long p = (unsigned long long)(a.out + (size_t)n * Ho * Wo * a.out_ps);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, Ho * Wo * a.out_ps * 4, 0x00020000);
+    };
+    const unsigned lane_chan = (unsigned)((a.out_coff + 4 * kg) * 4);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    dma_tile(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < a.tiles_total;                         // workgroup-uniform
+        if (has_next) dma_tile(next, buf ^ 1);                              // lands under this tile's MFMAs and stores
+
+        int n, chunk;
+        split(tile, n, chunk);
+        const __amdgpu_buffer_rsrc_t ro = out_rsrc(n);
+#pragma unroll
+        for (int t0 = 0; t0 < TN; t0 += TG) {   // TG column tiles at a time: 16 TG accumulator registers beside the CIN of the weights
+            f32x4 acc[TG][4];
+            // the quads of group g + 1 are requested before the MFMAs of group g (hipcc sinks LDS reads to their first use otherwise: an
+            // exposed LDS round trip per 32 MFMAs)
+            f32x4 px[TG], pxn[TG];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) px[t] = lds[buf * BUFQ + (t0 + t) * 16 * S + rd[0]];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g + 1 < G) {
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) pxn[t] = lds[buf * BUFQ + (t0 + t) * 16 * S + rd[g + 1]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < TG; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            if (g == 0 && j == 0) {
+                                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j][mt], px[t][j], zero, 0, 0, 0);
+                            } else {
+                                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j][mt], px[t][j], acc[t][mt], 0, 0, 0);
+                            }
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < G) {
+#pragma unroll
+                    for (int t = 0; t < TG; ++t) px[t] = pxn[t];
+                }
+            }
+            // ---- bias (no activation: app.py:96), tap (kh, kw) of pixel (y, x) -> output pixel (2y + kh, 2x + kw) ----
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const unsigned q = (unsigned)(chunk * TP + (t0 + t) * 16 + c16);
+                unsigned y = __umulhi(q, a.rcp_xy);                         // q / Win, at most one too large (q * (rcp * Win - 2^32) < 2^32 * Win)
+                int x = (int)(q - y * (unsigned)a.Win);
+                if (a.Win == 1) { y = q; x = 0; }
+                if (x < 0) { --y; x += a.Win; }
+                const bool ok = (int)q < HW && (int)y < a.Hc && x < a.Wc;
+                const unsigned po = ((2 * y + kh) * (unsigned)Wo + 2 * x + kw) * (unsigned)a.out_ps * 4 + lane_chan;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 v = acc[t][mt] + bias4[mt];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, ok ? po + mt * 64 : 0x7ffffff0u, 0, 0);
+                }
+            }
+        }
+        if (!has_next) break;
+        // this wave's DMA of the next tile was issued before the 4 TN stores above: all but those have completed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TN) : "memory");
+        __syncthreads();   // every wave's part of the next tile has landed, and every wave has left this tile's buffer
+        tile = next;
+        buf ^= 1;
+    }
+}
+
 }  // namespace cid

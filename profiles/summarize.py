@@ -27,7 +27,7 @@ from collections import defaultdict
 # kernel-name prefixes of the default fp32 forward (conv_algo = winograd42, fused last layer), launch order
 EXPECT = ["k_conv_head<", "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
           "k_wino42_conv<128, 256, false,", "k_wino42_conv<256, 256, false,", "k_gemm_conv<256, 128, 2,",
-          "k_wino42_conv<256, 128, false,", "k_wino42_conv<128, 128, false,", "k_gemm_conv<128, 64, 2,",
+          "k_wino42_conv<256, 128, false,", "k_wino42_conv<128, 128, false,", "k_convt_s32<128, 64>",
           "k_wino42_conv<128, 64, false,", "k_conv_tail_z<"]
 
 
