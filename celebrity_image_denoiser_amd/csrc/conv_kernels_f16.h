@@ -220,7 +220,11 @@ __device__ __forceinline__ void h16_store_row(float* stg, int lane, V value, _Fl
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
-        if (full || (rowok && px < xlim)) *reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8) = v;
+        // non-temporal: eight lanes write a pixel's whole 128-byte line, and the activations a launch writes (1 GB) are not read again
+        // before they have left the L2 anyway — but as ordinary stores they displace the input tiles that neighbouring workgroups are
+        // about to share (96 walkers x 44 KB of halo tile per XCD against 4 MB of L2).  Same box: every 3x3 launch -2...-6 %, head -5 %
+        // (profiles/r03_nt_stores.txt).  NOT for stores that rely on the L2 to merge partial lines (k_convt_t16: +50 %).
+        if (full || (rowok && px < xlim)) __builtin_nontemporal_store(v, reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8));
     }
     wave_lds_fence();
 }
