@@ -611,6 +611,34 @@ def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
     assert np.abs(_run(m, x) - g["out"]).max() <= TOL
 
 
+def test_fp16_ragged_shapes_and_long_walks(weight_sets):
+    """The half-storage kernels away from 128x128: (a) ragged sizes against the ATen oracle at the fp16 tolerance — image areas
+    that are not a multiple of the streaming transposed convolutions' 64 / 128-pixel runs (k_convt_t16 masks the run's tail per
+    lane), widths that are not a multiple of 16 (an MFMA column tile then spans two image rows), cropped odd sizes; (b) a batch long
+    enough that every persistent workgroup walks many runs (300 images: 9,600 runs of up1 for 512 workgroups, 4,800 of up2 for
+    256), built from four distinct images: every copy must come out bit-identical to the first, and the first four within
+    tolerance of the oracle (size-independent property: batch independence)."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from oracle import torch_oracle
+
+    m = cid.load(weight_sets["default"], device="cuda:0", strict=True)
+    m.compute_dtype = "f16"
+    for k, (n, h, w) in enumerate([(2, 52, 76), (3, 37, 150), (1, 100, 20), (2, 129, 67), (1, 8, 8)]):
+        x, _, _ = synth.make_batch(n, h, w, first_index=5000 + 10 * k)
+        y = _run(m, x)
+        ref = torch_oracle.forward(weight_sets["default"], x).numpy()
+        assert y.shape == ref.shape, (n, h, w)
+        assert np.abs(y - ref).max() <= 5e-4, (n, h, w, float(np.abs(y - ref).max()))
+    x4, _, _ = synth.make_batch(4, 128, 128, first_index=5100)
+    x = np.ascontiguousarray(np.tile(x4, (75, 1, 1, 1)))
+    y = _run(m, x)
+    ref = torch_oracle.forward(weight_sets["default"], x4).numpy()
+    assert np.abs(y[:4] - ref).max() <= 5e-4
+    y = y.reshape(75, 4, *y.shape[1:])
+    assert np.array_equal(y, np.broadcast_to(y[:1], y.shape))
+
+
 def test_host_pipeline_matches_direct_calls(models):
     """HostPipeline (upload / forward / download on three streams over two slots) returns, in order, exactly the
     bytes the plain calls return: uint8 and fp32 batches, a ragged last batch, a change of image size mid-stream,
