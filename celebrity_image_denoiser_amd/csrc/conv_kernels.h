@@ -1235,6 +1235,10 @@ __global__ void __launch_bounds__(THREADS, 2) k_convt_s32(const GemmConvArgs a) 
                     for (int t = 0; t < TG; ++t) px[t] = pxn[t];
                 }
             }
+            // The next tile's DMA (issued a whole tile of MFMAs ago) has landed for this wave before the LAST group's stores go out: waited
+            // for here, with nothing but long-finished requests outstanding, because vector loads and stores may complete out of order
+            // with respect to each other on gfx9 — a count taken after the stores would not single the loads out.
+            if (has_next && t0 + TG == TN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- bias (no activation: app.py:96), tap (kh, kw) of pixel (y, x) -> output pixel (2y + kh, 2x + kw) ----
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
@@ -1253,8 +1257,6 @@ __global__ void __launch_bounds__(THREADS, 2) k_convt_s32(const GemmConvArgs a) 
             }
         }
         if (!has_next) break;
-        // this wave's DMA of the next tile was issued before the 4 TN stores above: all but those have completed
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TN) : "memory");
         __syncthreads();   // every wave's part of the next tile has landed, and every wave has left this tile's buffer
         tile = next;
         buf ^= 1;

@@ -163,6 +163,10 @@ __global__ void __launch_bounds__(64 * 4 * (COUT / 64), 2) k_convt_t16(const Gem
                         }
                     }
                 }
+            // The next tile's DMA (issued a whole tile of MFMAs ago) has landed for this wave before the LAST group's stores go out: waited
+            // for here, with nothing but long-finished requests outstanding, because vector loads and stores may complete out of order
+            // with respect to each other on gfx9 — a count taken after the stores would not single the loads out.
+            if (has_next && t0 + TG == TN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- bias (no activation: app.py:89,96), one rounding to half, tap (kh, kw) of pixel (y, x) -> output pixel (2y + kh, 2x + kw) ----
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
@@ -186,8 +190,6 @@ __global__ void __launch_bounds__(64 * 4 * (COUT / 64), 2) k_convt_t16(const Gem
             }
         }
         if (!has_next) break;
-        // this wave's DMA of the next tile was issued before the 2 TN stores above: all but those have completed
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");
         __syncthreads();   // every wave's part of the next tile has landed, and every wave has left this tile's buffer
         tile = next;
         buf ^= 1;
