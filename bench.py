@@ -376,6 +376,10 @@ def main():
                 yh_ = mh(torch.from_numpy(xh_).to(dev)).cpu().numpy()
                 res["configs"][1]["max_abs_err_hot_weights"] = float(np.abs(yh_ - torch_oracle.forward(sd_hot, xh_).numpy()).max())
                 res["configs"][1]["hot_weights_images_checked"] = 16
+                res["configs"][1]["frac_note"] = (
+                    "layer_fracs of the MFMA-bound launches are against the nominal 2.5 PFLOP/s (2.4 GHz); this forward runs at the 1,400 W cap and "
+                    "holds 1.68-1.94 GHz in them (profiles/r03_f16_pmc.md, eff. clock from SQ_BUSY_CYCLES), i.e. 1.24-1.43x these fractions of what the "
+                    "part can issue at the clock it holds; up2, up1, head and last layer are HBM-bound (fraction of 8 TB/s)")
                 del mh
             except Exception as e:  # pragma: no cover
                 res["configs"] = {"error": str(e)[:300]}
