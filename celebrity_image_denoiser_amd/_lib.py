@@ -40,6 +40,7 @@ SYMBOLS = {
                                   _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "cid_forward_padded": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "cid_view_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "cid_forward_timed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.POINTER(_c.c_float)]),
     "cid_timing_begin": (_c.c_int, [_c.c_void_p, _c.c_int]),
@@ -62,6 +63,7 @@ SYMBOLS = {
     "cid_comm_unique_id": (_c.c_int, [_c.c_void_p]),
     "cid_comm_init_rank": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_void_p, _c.c_int]),
     "cid_comm_destroy": (_c.c_int, [_c.c_void_p]),
+    "cid_comm_count": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_broadcast_weights": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "cid_launch_work": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }

@@ -10,6 +10,8 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -412,15 +414,26 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
 // 75 KiB, <= 256 VGPRs) — the grid is what is resident and the workgroups WALK: a.walk = grid / 8 walkers per XCD group, each
 // taking tiles local, local + walk, ... with all NB column blocks of a tile back to back.  CID_WINO42_WG_PER_CU (environment) and
 // cid_debug_winograd_workgroups_per_cu (development / testing aids): 0 = never walk (the round-2 behaviour), k = k workgroups per CU.
-int g_wino42_wg_per_cu = [] { const char* e = std::getenv("CID_WINO42_WG_PER_CU"); return e ? std::atoi(e) : 2; }();
-int g_half_wg_per_cu = [] { const char* e = std::getenv("CID_HALF_WG_PER_CU"); return e ? std::atoi(e) : 3; }();   // k_conv3x3_h16, same meaning
+// The environment values are clamped like the debug setters' (0 = never walk ... the occupancy the kernel's LDS use admits).
+int env_wg_per_cu(const char* name, int dflt, int hi) {
+    const char* e = std::getenv(name);
+    if (!e) return dflt;
+    const int v = std::atoi(e);
+    return v < 0 ? 0 : v > hi ? hi : v;
+}
+int g_wino42_wg_per_cu = env_wg_per_cu("CID_WINO42_WG_PER_CU", 2, 2);
+int g_half_wg_per_cu = env_wg_per_cu("CID_HALF_WG_PER_CU", 3, 3);   // k_conv3x3_h16, same meaning
+// CU count of the CURRENT device (the one the launch goes to), cached per device id: a process may drive unlike devices.
 int device_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
-    return cus;
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 int wino42_grid(WinoArgs& a, int nb) {
     const int per_cu = g_wino42_wg_per_cu;
@@ -428,7 +441,10 @@ int wino42_grid(WinoArgs& a, int nb) {
     const int items = 8 * a.tiles_per_xcd * nb;
     const int walkers = per_cu * cus / 8;                    // per XCD group
     a.walk = 0;
-    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers) return items;
+    // Walkers are indexed by TILE (a walker runs all nb column blocks of its tiles back to back), so walking needs at least one
+    // tile per walker: with fewer, only tiles_per_xcd of the slots would work, each nb items deep, where one item per workgroup
+    // spreads the same items over every CU (mid-size batches, N = 17..48 on the bottleneck layers).
+    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers || a.tiles_per_xcd < walkers) return items;
     a.walk = walkers;
     return 8 * walkers;
 }
@@ -548,7 +564,7 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         // sibling workgroups dispatched back to back share one fetch (profiles/r03_ab_f16_walk.txt).
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
-        if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers) { a.walk = walkers; grid = 8 * walkers; }
+        if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
         hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();
@@ -843,6 +859,15 @@ int cid_forward_padded(cid_handle_t h, const void* in, int in_fmt, void* out, in
     return rc;
 }
 
+int cid_view_u8(const float* in_nchw, void* out_u8_nhwc, int N, int H, int W, void* stream) {
+    if (!in_nchw || !out_u8_nhwc || N < 1 || H < 1 || W < 1) return CID_ERR_INVALID;
+    const size_t plane = (size_t)H * W, pixels = plane * N;
+    if ((pixels + THREADS - 1) / THREADS > 0x7fffffffull) return CID_ERR_SHAPE;
+    hipLaunchKernelGGL(k_view_u8, dim3((unsigned)((pixels + THREADS - 1) / THREADS)), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       in_nchw, static_cast<unsigned char*>(out_u8_nhwc), plane, pixels);
+    return hipGetLastError() == hipSuccess ? CID_OK : CID_ERR_HIP;
+}
+
 int cid_debug_winograd_workgroups_per_cu(int k) {
     const int prev = g_wino42_wg_per_cu;
     if (k >= 0) g_wino42_wg_per_cu = k > 2 ? 2 : k;   // two is what the kernel's LDS use (75 KiB) admits
@@ -1007,8 +1032,9 @@ struct Rccl {
     typedef int (*CommDestroy)(void*);
     typedef int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
     typedef const char* (*GetErrorString)(int);
+    typedef int (*CommCount)(void*, int*);
     GetUniqueId get_unique_id = nullptr; CommInitRank comm_init_rank = nullptr; CommDestroy comm_destroy = nullptr;
-    Broadcast broadcast = nullptr; GetErrorString error_string = nullptr;
+    Broadcast broadcast = nullptr; GetErrorString error_string = nullptr; CommCount comm_count = nullptr;
     std::string why;
     bool ok = false;
 };
@@ -1025,6 +1051,7 @@ const Rccl& rccl() {
         x.comm_destroy = (Rccl::CommDestroy)dlsym(lib, "ncclCommDestroy");
         x.broadcast = (Rccl::Broadcast)dlsym(lib, "ncclBroadcast");
         x.error_string = (Rccl::GetErrorString)dlsym(lib, "ncclGetErrorString");
+        x.comm_count = (Rccl::CommCount)dlsym(lib, "ncclCommCount");   // optional: only cid_comm_count needs it
         x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.broadcast && x.error_string;
         if (!x.ok) x.why = "librccl.so.1 lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclBroadcast";
         return x;
@@ -1054,6 +1081,11 @@ int cid_comm_destroy(void* comm) {
     if (!comm) return CID_ERR_INVALID;
     if (!rccl().ok) return CID_ERR_STATE;
     return rccl().comm_destroy(comm) == 0 ? CID_OK : CID_ERR_HIP;
+}
+int cid_comm_count(void* comm, int* nranks) {
+    if (!comm || !nranks) return CID_ERR_INVALID;
+    if (!rccl().ok || !rccl().comm_count) return CID_ERR_STATE;
+    return rccl().comm_count(comm, nranks) == 0 ? CID_OK : CID_ERR_HIP;
 }
 
 int cid_broadcast_weights(cid_handle_t h, void* comm, int root, int rank, void* stream) {

@@ -1081,6 +1081,24 @@ __global__ void __launch_bounds__(THREADS) k_conv_tail_z(const TailZArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The reference's view transform as a stand-alone pass (app.py:435 `y*0.5+0.5` clamp(0,1), :471-472 ToPILImage = mul(255).byte(),
+// truncating; denoise_eavl_iter.py:97-110 saves such a view of EVERY fed-back iteration): fp32 NCHW tanh-range tensor -> uint8 NHWC
+// image, the same arithmetic as k_conv_tail_z<true>'s store.  For callers that need both the fp32 tensor (fed back) and its image.
+// One thread per pixel: three coalesced plane reads, three bytes out.  HBM-bound, 15 B per pixel.
+__global__ void __launch_bounds__(THREADS) k_view_u8(const float* __restrict__ in, unsigned char* __restrict__ out, size_t plane, size_t pixels) {
+    const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;    // pixel index over the batch
+    if (i >= pixels) return;
+    const size_t n = i / plane, p = i - n * plane;
+    const float* ip = in + n * 3 * plane + p;
+    unsigned char* op = out + i * 3;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        const float v = fminf(fmaxf(ip[co * plane] * 0.5f + 0.5f, 0.f), 1.f);
+        op[co] = (unsigned char)(v * 255.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_convt_s32 — up1 = ConvTranspose2d(128, 64, 2, stride=2) (app.py:73,96) as a streaming kernel (round 3; the fp16 path's k_convt_t16
 // is the same design, conv_kernels_f16.h).  A 2x2 stride-2 transposed convolution has no halo: every input pixel is read once and
 // produces four output pixels.  k_gemm_conv MODE 2 ran it at 0.75 of the fp32 MFMA peak: one workgroup per (8x32 tile, tap), weights
@@ -1167,8 +1185,8 @@ __global__ void __launch_bounds__(THREADS, 2) k_convt_s32(const GemmConvArgs a) 
 #pragma unroll
         for (int j = 0; j < ROUNDS; ++j) {
             const int base = chunk * TP + (j / NV) * 16;                   // pixel of the image that round j - j % NV starts at
-            const int q = base + pl[j % NV];                               // beyond the image: zeros (offset out of range — the scalar
-            const unsigned vo = q < HW ? dma_lane[j % NV] : 0x7ffffff0u;   // offset is not part of the hardware's range check)
+            const int q = base + pl[j % NV];                               // beyond the image: zeros.  The mask is carried by the PER-LANE
+            const unsigned vo = q < HW ? dma_lane[j % NV] : 0x7ffffff0u;   // offset: nothing relies on the scalar offset being range-checked
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)&lds[buf * BUFQ + (j * NW + wave) * 64], 16, vo,
                                                      base * a.in_ps * 4, 0, 0);
         }

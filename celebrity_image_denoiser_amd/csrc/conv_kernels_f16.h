@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(64 * 4 * (COUT / 64), 2) k_convt_t16(const Gem
         const __amdgpu_buffer_rsrc_t rsrc = image_rsrc(n);
 #pragma unroll
         for (int j = 0; j < ROUNDS; ++j) {
-            const int q = chunk * TP + j * 16 + pl0;                       // pixel of the image; beyond it: zeros (offset out of range —
-            const unsigned vo = q < HW ? dma_lane : 0x7ffffff0u;           // the scalar offset is not part of the hardware's range check)
+            const int q = chunk * TP + j * 16 + pl0;                       // pixel of the image; beyond it: zeros.  The mask is carried by the
+            const unsigned vo = q < HW ? dma_lane : 0x7ffffff0u;           // PER-LANE offset: nothing relies on the scalar offset being range-checked
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)&lds[buf * BUFQ + (j * NW + wave) * 64], 16, vo,
                                                      (chunk * TP + j * 16) * a.in_ps * 2, 0, 0);
         }

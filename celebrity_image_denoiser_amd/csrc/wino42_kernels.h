@@ -557,8 +557,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const int tile = 4 * q + W, ttr = tile / TC, ttc = tile - ttr * TC;          // compile-time
                 const int yb = y0 + 2 * ttr, xx = x0 + 4 * ttc;                             // scalar
-                const unsigned soff = xx < a.Ws ? (unsigned)((yb * a.Ws + xx) * 4) : 0x7ffffff0u;
-                const unsigned vo = (i32 < 27 && yb + h < a.Hs) ? zlane : 0x7ffffff0u;
+                // masking lives in the PER-LANE offset only (as in every other store here): whether the scalar offset takes part
+                // in the hardware range check is not documented for stores, so nothing may depend on it
+                const bool in_x = xx < a.Ws;                                                // scalar
+                const unsigned soff = in_x ? (unsigned)((yb * a.Ws + xx) * 4) : 0u;
+                const unsigned vo = (in_x && i32 < 27 && yb + h < a.Hs) ? zlane : 0x7ffffff0u;
                 store16(f32x4{zacc[4 * q], zacc[4 * q + 1], zacc[4 * q + 2], zacc[4 * q + 3]}, rz, vo, soff);
             }
             return;

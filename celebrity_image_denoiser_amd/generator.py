@@ -319,6 +319,25 @@ class DenoiseGenerator(nn.Module):
                                                        n, h, w, left, top, right, bottom, self._ws.data_ptr(), self._ws.numel(), stream))
         return y
 
+    @staticmethod
+    def view_u8(y: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """The reference's image view of a tanh-range tensor (app.py:435,471-472: y*0.5+0.5, clamp, mul(255).byte()) as one HIP
+        kernel (cid_view_u8): fp32 [N,3,H,W] on the GPU -> uint8 [N,H,W,3].  What `forward_fmt(out_u8=True)` would have stored,
+        for callers that also keep `y` itself (the iterated denoise feeds it back, denoise_eavl_iter.py:93-110)."""
+        if not isinstance(y, torch.Tensor) or y.dim() != 4 or y.shape[1] != 3 or y.dtype != torch.float32:
+            raise RuntimeError("view_u8 expects a float32 tensor of shape [N,3,H,W]")
+        if y.device.type != "cuda":
+            raise RuntimeError("got a CPU tensor: this implementation is GPU-only; there is no CPU fallback")
+        n, _, h, w = y.shape
+        if n < 1 or h < 1 or w < 1:
+            raise RuntimeError("empty tensor")
+        y = y.contiguous()
+        img = DenoiseGenerator._output(out, (n, h, w, 3), torch.uint8, y.device)
+        stream = torch.cuda.current_stream(y.device).cuda_stream
+        with torch.cuda.device(y.device):
+            _lib.check(None, _lib.lib().cid_view_u8(y.data_ptr(), img.data_ptr(), n, h, w, stream))
+        return img
+
     def forward_timed(self, x: torch.Tensor):
         """forward + per-launch milliseconds from HIP events on the launch stream (measurement aid)."""
         x, y, n, h, w = self._prepare(x)

@@ -84,7 +84,7 @@ def enhance_images(checkpoint_path, input_dir: str = "testNoise", output_dir: st
                         z = model(z)
                     last = it == num_iterations
                     if save_intermediates or last:
-                        view = api.to_unit_range(z).mul(255).byte().permute(0, 2, 3, 1).contiguous().cpu().numpy()
+                        view = model.view_u8(z).cpu().numpy()     # the reference's *0.5+0.5 / clamp / ToPILImage view, one HIP kernel (cid_view_u8)
                         for k, (f, _) in enumerate(ok):
                             base, ext = os.path.splitext(f)
                             if save_intermediates:

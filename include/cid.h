@@ -125,6 +125,14 @@ int cid_forward_ex(cid_handle_t h, const void* in, int in_fmt, void* out, int ou
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The reference's view transform alone — backend/app.py:435 (y*0.5+0.5, clamp to [0,1]) and :471-472 (ToPILImage: mul(255).byte(),
+ * truncating), as the iterated caller applies it to EVERY fed-back iteration (denoise_eavl_iter.py:97-110): a device fp32
+ * [N,3,H,W] tensor in tanh range -> device uint8 [N,H,W,3].  Same arithmetic as cid_forward_ex's CID_FMT_U8_NHWC output, for callers that
+ * keep the fp32 tensor (to feed it back) and also want its image.  No handle: it needs no weights.
+ */
+int cid_view_u8(const float* in_nchw, void* out_u8_nhwc, int N, int H, int W, void* stream);
+
+/*
  * The reference server's handling of arbitrary upload sizes (backend/app.py:276-281 get_padding, :384-385
  * transforms.Pad(padding, fill=0) in front of ToTensor/Normalize, :474-480 crop of the result), as index arithmetic in the
  * first and the last kernel — no padded copy of the image and no uncropped output exist:
@@ -238,6 +246,7 @@ int cid_comm_available(void);   /* 1 if RCCL could be resolved in this process (
 int cid_comm_unique_id(void* id128);
 int cid_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
 int cid_comm_destroy(void* comm);
+int cid_comm_count(void* comm, int* nranks);   /* ncclCommCount: how many ranks RCCL itself says the communicator spans */
 int cid_broadcast_weights(cid_handle_t h, void* comm, int root, int rank, void* stream);
 
 /*

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "cid.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(cid_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(cid_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_header_symbol():
@@ -78,6 +78,9 @@ def test_oversize_image_is_an_error_not_wrong_borders():
     assert pad(30, 45, -1, 1, 2, 1) == 1 and pad(30, 45, 1, 1, 2, 5000) == 1             # bad paddings
     assert pad(1, 1, 0, 0, 1, 1) == 2 and b"too small" in L.cid_last_error(h)            # padded image 2 x 2
     assert pad(2040, 2040, 4, 4, 4, 4) == 2 and b"too large" in L.cid_last_error(h)      # the PADDED size counts for the one-call limit
+    # cid_view_u8 (the reference's *0.5+0.5 / clamp / ToPILImage view as a stand-alone pass): argument checks only, no launch
+    assert L.cid_view_u8(None, fake, 1, 4, 4, None) == 1 and L.cid_view_u8(fake, None, 1, 4, 4, None) == 1
+    assert L.cid_view_u8(fake, fake, 0, 4, 4, None) == 1 and L.cid_view_u8(fake, fake, 1, 0, 4, None) == 1
     L.cid_destroy(h)
 
 

@@ -33,7 +33,8 @@ def _worker(rank, world, port, out_dir):
         model = cid.DenoiseGenerator()
         if rank == 0:
             model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("hot").items()})
-        cdist.broadcast_weights(model, src=0)
+        info = cdist.broadcast_weights_ex(model, src=0)
+        assert info["transport"] == "host" and info["nranks"] is None and info["broadcast_ms"] > 0.0   # CPU ranks: the host blob over gloo
         ref = synth.make_state_dict("hot")
         same = all(np.array_equal(model.state_dict()[k].numpy(), ref[k]) for k in ref)
         begin, end = cdist.shard_range(11, rank, world)
@@ -91,7 +92,13 @@ def _negotiation_worker(rank, world, port, out_dir, scenario):
 
         cdist.WeightsComm._make_unique_id = staticmethod(make_id)
         cdist.WeightsComm._init_rank = staticmethod(init_rank)
-        comm = cdist.WeightsComm.negotiate(torch.device("cpu"))
+        if scenario == "cached":
+            # the communicator is made once per (group, device) and kept: the second request makes no collective
+            comm, fresh = cdist.WeightsComm.for_group(torch.device("cpu"))
+            again, fresh2 = cdist.WeightsComm.for_group(torch.device("cpu"))
+            assert fresh and not fresh2 and again is comm and comm is not None
+        else:
+            comm = cdist.WeightsComm.negotiate(torch.device("cpu"))
         got = "comm" if comm is not None else "none"
         # a collective AFTER the negotiation: it only completes if both ranks left negotiate() in step
         t = torch.tensor([rank + 1.0])
@@ -109,6 +116,7 @@ def test_transport_negotiation_never_leaves_a_rank_behind(tmp_path):
     transport 2 together.  The old code raised on rank 0 before the id exchange and left rank 1 inside broadcast_object_list."""
     want = {
         "all_fine": ("comm sum=3 closed_early=[]", "comm sum=3 closed_early=[]"),
+        "cached": ("comm sum=3 closed_early=[]", "comm sum=3 closed_early=[]"),
         "rccl_missing_on_rank1": ("none sum=3 closed_early=[]", "none sum=3 closed_early=[]"),
         "unique_id_fails_on_rank0": ("none sum=3 closed_early=[]", "none sum=3 closed_early=[]"),
         # rank 0 did set its communicator up: it is destroyed again before falling back

@@ -223,6 +223,18 @@ def test_iterated_denoise_golden(models, golden_dir, wset):
     u8 = to_unit_range(y3).mul(255).byte().permute(0, 2, 3, 1).numpy()
     d = np.abs(u8.astype(np.int16) - g["final_u8"].astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+    # ... which the product takes with one HIP kernel (cid_view_u8, harness.enhance_images): the same bytes as the expression above,
+    # and as the uint8 output format of the forward that produced y3 (cid_forward_ex) would have held
+    y3d = y3.to("cuda:0")
+    assert np.array_equal(m.view_u8(y3d).cpu().numpy(), u8)
+    y2d = cid.denoise(m, x, iterations=2).to("cuda:0")
+    assert torch.equal(m.view_u8(m(y2d)), m.forward_fmt(y2d, out_u8=True))
+    edge = torch.tensor([-1.5, -1.0, -0.999, -0.5, 0.0, 0.25, 0.999, 1.0, 1.5, float("nan")] * 12, device="cuda:0").view(1, 3, 5, 8)   # clamp ends, NaN -> 0 like fmaxf/fminf
+    got = m.view_u8(edge).cpu().numpy()
+    ok = ~torch.isnan(edge).cpu().numpy().transpose(0, 2, 3, 1)
+    assert np.array_equal(got[ok], to_unit_range(edge).mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()[ok])
+    with pytest.raises(RuntimeError):
+        m.view_u8(y3)                                               # CPU tensor: no fallback
 
 
 def test_load_checkpoint_by_path_and_run(tmp_path, golden_dir, weight_sets):
@@ -785,7 +797,10 @@ def test_rccl_broadcast_through_the_c_abi(weight_sets):
         src = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
         x, _, _ = synth.make_batch(2, 32, 32, first_index=1400)
         want = _run(src, x)
-        cdist.broadcast_weights(src, src=0)                 # comm init + ncclBroadcast (root side) + comm destroy
+        first = cdist.broadcast_weights_ex(src, src=0)      # communicator set-up + ncclBroadcast (root side); the communicator is kept
+        assert first["transport"] == "rccl-cabi" and first["nranks"] == 1 and first["setup_ms"] > 0.0   # nranks: what RCCL itself reports
+        again = cdist.broadcast_weights_ex(src, src=0)      # second broadcast: the cached communicator, only the transfer
+        assert again["transport"] == "rccl-cabi" and again["setup_ms"] == 0.0 and again["broadcast_ms"] < first["setup_ms"]
         assert np.array_equal(_run(src, x), want)
         assert L_available()
         comm = cdist.WeightsComm.negotiate(torch.device("cuda:0"))
@@ -805,8 +820,8 @@ def test_rccl_broadcast_through_the_c_abi(weight_sets):
         assert L.cid_broadcast_weights(h, ctypes.c_void_p(8), 0, 0, None) == 4 and b"no device blob" in L.cid_last_error(h)
         L.cid_destroy(h)
     finally:
+        cdist.WeightsComm.close_all()
         dist.destroy_process_group()
-
 
 
 def test_striped_forward_equals_single_call_bit_for_bit(models):
@@ -897,3 +912,102 @@ def test_no_kernel_reads_unwritten_lds_or_arena(models, weight_sets, dtype):
                 assert torch.equal(got, ref), (dtype, n, h, w)
     finally:
         m.compute_dtype = "f32"
+
+
+@pytest.mark.parametrize("wset", ["default", "hot"])
+def test_white_noise_inputs_stay_within_the_fp32_contract(models, weight_sets, wset):
+    """VERDICT r3 #4(i).  The reference accepts ANY image in [-1, 1] (app.py:400-406), not only the smooth face-like fields the
+    benchmark batch is made of; white noise is the worst case for the Winograd transforms' rounding (no cancellation between
+    neighbouring pixels).  Uniform noise in [-1, 1] at a ragged width (128 x 134: partial tiles at the right edge), every
+    algorithm (module fixture) x both weight sets against the ATen oracle at the stated 1e-5.  Measured in round 3 with the
+    ad-hoc tools/noise_err.py: 4e-6 ... 7e-6 on the He-gain set (the 9-tap direct kernel the largest), 3e-8 at default scale."""
+    from oracle import torch_oracle
+
+    g = torch.Generator(device="cpu")
+    g.manual_seed(99)
+    x = (torch.rand((6, 3, 128, 134), generator=g) * 2 - 1).contiguous().numpy()
+    ref = torch_oracle.forward(weight_sets[wset], x).numpy()
+    y = _run(models[wset], x)
+    assert y.shape == ref.shape == (6, 3, 128, 132)
+    err = float(np.abs(y - ref).max())
+    assert err <= TOL, (models[wset].conv_algo, wset, err)
+    # the extreme members of the contract: a saturated checkerboard (every pixel +-1, sign alternating per pixel and channel)
+    yy, xx = np.mgrid[0:64, 0:64]
+    cb = np.stack([((yy + xx + c) % 2) * 2.0 - 1.0 for c in range(3)]).astype(np.float32)[None]
+    err_cb = float(np.abs(_run(models[wset], cb) - torch_oracle.forward(weight_sets[wset], cb).numpy()).max())
+    assert err_cb <= TOL, (models[wset].conv_algo, wset, err_cb)
+
+
+def test_config3_full_size_256x256_batch_256(weight_sets):
+    """BASELINE configs[3] at its REAL size — B = 256 images of 256 x 256 (31.7 GB arena) — which the suite so far
+    saw only at N = 1.  Size-independent properties, on the default algorithm: (a) batch independence: three images of the
+    full batch equal, bit for bit, the same images run alone (different grids: the full batch walks, a single image does not);
+    (b) one image against the CPU oracle at 1e-5; (c) every stored stage of the walking launch equals the one-item-per-workgroup
+    launch bit for bit."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import _lib
+    from oracle import torch_oracle
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~70 GiB of free device memory")
+    L = _lib.lib()
+    B, S = 256, 256
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    base, _, _ = synth.make_batch(8, S, S, first_index=9100)                # eight distinct images, tiled to the full batch
+    xd = torch.from_numpy(base).to("cuda:0").repeat(B // 8, 1, 1, 1).contiguous()
+    stages = ["down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1"]
+    prev = L.cid_debug_winograd_workgroups_per_cu(-1)
+    try:
+        y = m(xd)
+        torch.cuda.synchronize()
+        probe = (0, 131, 255)
+        walk_stage = {s: m.stage_output(s, B, S, S)[list(probe)].clone() for s in stages}
+        for i in probe:                                                     # (a)
+            assert torch.equal(m(xd[i:i + 1].contiguous()), y[i:i + 1]), i
+        for k in range(8, B, 8):                                            # copies of the same eight images: identical bits
+            assert torch.equal(y[k:k + 8], y[:8]), k
+        ref = torch_oracle.forward(weight_sets["hot"], base[:1]).numpy()    # (b)
+        err = float(np.abs(y[:1].cpu().numpy() - ref).max())
+        assert err <= TOL, err
+        L.cid_debug_winograd_workgroups_per_cu(0)                           # (c)
+        y_one = m(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(y_one, y)
+        for s in stages:
+            one = m.stage_output(s, B, S, S)[list(probe)]
+            assert torch.equal(one, walk_stage[s]), (s, int((one != walk_stage[s]).sum()))
+    finally:
+        L.cid_debug_winograd_workgroups_per_cu(prev)
+        del xd
+        m._ws = None
+        torch.cuda.empty_cache()
+
+
+def test_fp16_storage_contract_on_he_gain_weights_16_images(weight_sets):
+    """BASELINE.md section 4 states max|delta| <= 5e-3 for configs[4] (fp16 storage, fp16 MFMA, fp32 accumulate).
+    Until now the 16-image He-gain measurement lived only in bench.py's configs leg (3.0e-3); here it is a test: 16 images of
+    128 x 128 from the benchmark's generator, He-gain ("hot") weights (activations up to ~5, tanh to +-0.98), against the fp32
+    ATen oracle; and the PSNR of the result against the clean images within 0.05 dB of the fp32 reference's."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from celebrity_image_denoiser_amd import psnr
+    from oracle import torch_oracle
+
+    m = cid.load(weight_sets["hot"], device="cuda:0", strict=True)
+    m.compute_dtype = "f16"
+    x, clean, _ = synth.make_batch(16, 128, 128, first_index=100)
+    y = _run(m, x)
+    ref = torch_oracle.forward(weight_sets["hot"], x).numpy()
+    err = float(np.abs(y - ref).max())
+    assert err <= 5e-3, err
+    assert abs(psnr(y, clean) - psnr(ref, clean)) <= 0.05
+    # and at full batch (B = 512, configs[4]'s size): the first 16 images of the big batch are the bits of the 16 run alone
+    xb = torch.from_numpy(x).to("cuda:0").repeat(32, 1, 1, 1).contiguous()
+    yb = m(xb)
+    torch.cuda.synchronize()
+    assert torch.equal(yb[:16].cpu(), torch.from_numpy(y)) and torch.equal(yb[496:], yb[:16])
+    del xb, yb
+    m._ws = None
+    torch.cuda.empty_cache()

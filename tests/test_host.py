@@ -318,3 +318,96 @@ def test_no_unpadded_store_data_hazard_in_the_kernels(tmp_path):
     assert out.returncode == 0, out.stdout
     n = int(out.stdout.split(":")[1].split()[0])
     assert n >= 100, out.stdout          # the scan did see the Winograd epilogue's stores
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_self_launch_starts_one_child_per_gpu_and_relays_rank0(tmp_path):
+    """`python bench.py --gpus N` as a plain command (the form the driver records) must run by itself.  The
+    launcher (bench.launch_ranks) starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / one shared
+    free MASTER_PORT, passes the command line through, relays rank 0's single stdout line and returns 0.  The child command is
+    a stand-in here (no GPU); importing bench.py must not import torch or touch the library (the launcher stays GPU-free)."""
+    import io
+    import json
+    import subprocess
+    import sys
+
+    probe = subprocess.run([sys.executable, "-c",
+                            "import sys, importlib.util as u; s = u.spec_from_file_location('b', sys.argv[1]); m = u.module_from_spec(s); "
+                            "s.loader.exec_module(m); print('torch' in sys.modules, 'celebrity_image_denoiser_amd' in sys.modules)",
+                            os.path.join(ROOT, "bench.py")], capture_output=True, text=True, check=True)
+    assert probe.stdout.split() == ["False", "False"]
+    bench = _load_bench()
+    child = ("import json, os, sys\n"
+             "e = {k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')}\n"
+             "e['argv'] = sys.argv[1:]\n"
+             f"json.dump(e, open(os.path.join({str(tmp_path)!r}, 'rank' + e['RANK'] + '.json'), 'w'))\n"
+             "print('noise from rank ' + e['RANK'], file=sys.stderr)\n"
+             "print(json.dumps({'metric': 'stub', 'n_gpus': int(e['WORLD_SIZE']), 'from_rank': int(e['RANK'])}))\n")
+    out = io.StringIO()
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    rc = bench.launch_ranks(4, argv, child_cmd=[sys.executable, "-c", child], out=out)
+    assert rc == 0
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "stub", "n_gpus": 4, "from_rank": 0}   # only rank 0's stdout is relayed
+    envs = [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(4)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["LOCAL_WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and int(envs[0]["MASTER_PORT"]) > 0
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["argv"] == argv for e in envs)
+
+
+def test_bench_self_launch_propagates_a_failing_rank(tmp_path):
+    """A rank that exits non-zero makes the launcher return that code promptly and stop the other ranks (they would wait for
+    it inside a collective); nothing of a failed run is mistaken for a result line."""
+    import io
+    import sys
+    import time
+
+    bench = _load_bench()
+    child = ("import os, sys, time\n"
+             "r = int(os.environ['RANK'])\n"
+             f"open(os.path.join({str(tmp_path)!r}, 'started%d' % r), 'w').close()\n"
+             "if r == 2:\n"
+             "    time.sleep(0.5); sys.exit(7)\n"
+             "time.sleep(120)\n"
+             "print('{\"never\": 1}')\n")
+    out = io.StringIO()
+    t0 = time.time()
+    rc = bench.launch_ranks(3, [], child_cmd=[sys.executable, "-c", child], out=out)
+    assert rc == 7 and time.time() - t0 < 60 and out.getvalue().strip() == ""
+    assert all(os.path.exists(os.path.join(tmp_path, f"started{r}")) for r in range(3))
+
+
+def test_bench_plain_command_with_gpus_n_uses_the_launcher(monkeypatch):
+    """main(): --gpus N > 1 without WORLD_SIZE goes to launch_ranks with the untouched command line and exits with its code;
+    with WORLD_SIZE set (a rank started by torch.distributed.run or by the launcher) it does not."""
+    import sys
+
+    bench = _load_bench()
+    seen = {}
+
+    def fake(n, argv, **kw):
+        seen.update(n=n, argv=list(argv))
+        return 5
+
+    monkeypatch.setattr(bench, "launch_ranks", fake)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 5 and seen == {"n": 8, "argv": ["--gpus", "8", "--steps", "20", "--warmup", "5"]}
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(bench, "_import_runtime", lambda: (_ for _ in ()).throw(KeyboardInterrupt("reached the rank path")))
+    with pytest.raises(KeyboardInterrupt):
+        bench.main()
+    assert seen == {}
