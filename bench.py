@@ -193,9 +193,22 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
             traffic = next((v for k, v in tr.items() if k.startswith(d["kernel"])), None)
         except Exception:
             traffic = None
+    alu = None
+    pmc_alu = os.path.join(ROOT, "profiles", "pmc_alu.json")   # from the `pmc_alu` pass of profiles/collect.sh (SQ_INSTS_VALU / _MFMA, MFMA busy)
+    if os.path.exists(pmc_alu) and not f16:
+        try:
+            alu = next((v for k, v in json.load(open(pmc_alu)).items() if k.startswith(d["kernel"])), None)
+        except Exception:
+            alu = None
     if d["bound"] == "mfma":
         roof = {"bound": "mfma", "achieved": d["tflops_executed"], "peak": peak_tf, "unit": "TFLOP/s", "frac": d["frac"],
                 "traffic": traffic, "achieved_algorithmic": d["tflops_algorithmic"]}
+        if alu is not None:
+            # the fp32 MFMA shares the SIMD's ALUs with every other vector instruction: (MFMA busy cycles + plain VALU instructions x 4
+            # issue cycles) / SIMD cycles, from PMC counters of a profiled run of this command (profiles/README.md)
+            roof["alu_frac"] = round(alu["alu_frac"], 4)
+            roof["alu_note"] = (f"PMC pass: MFMA busy {alu['mfma_busy_frac']:.3f} of SIMD cycles + {alu['valu_per_mfma']:.2f} plain VALU instructions per MFMA "
+                                f"x 4 cycles (x 2.8: {alu['alu_frac_c2p8']:.3f}); at the clock the part holds, not the nominal 2.4 GHz")
         if "wino" in d["kernel"]:
             roof["note"] = ("achieved = FLOPs the matrix pipe executes (Winograd F(4x2,3x3): 24/72, F(2x2,3x3): 16/36 of the direct-convolution count) / "
                             "mean launch time; achieved_algorithmic = direct-convolution FLOPs (SURVEY 8a) / the same time")

@@ -209,10 +209,12 @@ size_t packed_index_ht(const LayerDef& L, int co, int ci, int kh, int kw) {
     return (((((size_t)(tap * CB + cb) * KS + ks) * 4 + mt) * 64) + kga * 16 + row) * 8 + e;
 }
 
-// k_conv3x3_h16: [nb][32-ch chunk][dx][dy][cg = (co/16)%4][lane = 16*kg + co%16][8] halfs with ci = 32*chunk + 8*kg + e —
-// lane (col, kg) of v_mfma_f32_16x16x32_f16 holds B[k = 8kg..8kg+7][col]; one (chunk, dx) is a 12 KiB LDS-DMA unit.
+// k_conv3x3_h16: [nb][32-ch chunk][dx][dy][cg = co%4][lane = 16*kg + (co/4)%16][8] halfs with ci = 32*chunk + 8*kg + e —
+// lane (col, kg) of v_mfma_f32_16x16x32_f16 holds B[k = 8kg..8kg+7][col]; column col of channel group cg is output channel
+// 64 nb + 4 col + cg, so a lane's four accumulator tiles are four consecutive channels (the kernel stores them as 8 bytes);
+// one (chunk, dx) is a 12 KiB LDS-DMA unit.
 size_t packed_index_h16(const LayerDef& L, int co, int ci, int kh, int kw) {
-    const int nb = co >> 6, cg = (co >> 4) & 3, c = co & 15;
+    const int nb = co >> 6, cg = co & 3, c = (co >> 2) & 15;
     const int ck = ci >> 5, kg = (ci >> 3) & 3, e = ci & 7;
     const int nchunk = L.cin / 32;
     return ((((((size_t)(nb * nchunk + ck) * 3 + kw) * 3 + kh) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
@@ -732,13 +734,13 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                 hd[L.kind == CONV ? packed_index_h16(L, co, ci, kh, kw) : packed_index_ht(L, co, ci, kh, kw)] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
         }
-        if (L.kind == HEAD) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = co % 16, kg) of group co / 16 holds k = 8kg..8kg+7
+        if (L.kind == HEAD) {   // k_conv_head_h16: B[k = 3 tap + c][co], rows 27..31 zero; lane (col = (co / 4) % 16, kg) of group co % 4 holds k = 8kg..8kg+7
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for (int co = 0; co < 64; ++co)
                 for (int k = 0; k < 32; ++k) {
                     const int tap = k / 3, c = k % 3;
                     const float v = k < 27 ? data[ref_index(L, co, c, tap / 3, tap % 3)] : 0.f;
-                    hd[((co >> 4) * 64 + (k >> 3) * 16 + (co & 15)) * 8 + (k & 7)] = (_Float16)v;
+                    hd[((co & 3) * 64 + (k >> 3) * 16 + ((co >> 2) & 15)) * 8 + (k & 7)] = (_Float16)v;
                 }
         }
     }

@@ -199,54 +199,51 @@ __global__ void __launch_bounds__(64 * 4 * (COUT / 64), 2) k_convt_t16(const Gem
 // Row permutation of the 16x16x32 kernels: MFMA row i of a 16-pixel group is pixel h16_prow(i) = {2,0,8,10}[i/4] + (i&1) + 4*((i>>1)&1).
 __device__ __forceinline__ int h16_prow(int i) { return ((0xa802 >> (4 * (i >> 2))) & 15) + (i & 1) + 2 * (i & 2); }
 
-// Stores of the 16x16x32 kernels.  In an accumulator tile, lane (channel c16 = lane & 15 of group cg, row group kg = lane >> 4) holds
-// pixels 16 pg + {2,0,8,10}[kg] + (r&1) + 4(r>>1) (r = 0..3) of one output row.  h16_store_row stages NPIX = 32 such pixels (or the
-// NPIX = 16 pooled ones, 8 pg + {1,0,4,5}[kg] + 2r, r = 0..1) x 64 channels as fp32 in `stg` (WS_FLOATS floats, wave-private: no
-// workgroup barrier inside), rounds once to half and writes 16 bytes per lane.  value(pg, cg, r) yields the finished fp32 element.
+// Stores of the 16x16x32 kernels (round 4: straight from the accumulators).  Column j of channel group cg is output channel 4 j + cg of
+// the workgroup's 64 (packed_index_h16 / the head's packing put the weights there): in an accumulator tile, lane (column c16 = lane & 15,
+// row group kg = lane >> 4) holds pixels 16 pg + {2,0,8,10}[kg] + (r&1) + 4(r>>1) (r = 0..3) of one output row, and its four channel
+// groups are four CONSECUTIVE channels 4 c16 .. 4 c16 + 3 — 8 bytes as halfs.  A store instruction therefore writes four pixels'
+// whole 128-byte lines (16 lanes each) with no pass through LDS: rounds 2-3 staged every row as fp32 in a wave-private LDS area
+// (32 ds_write_b32 + 8 ds_read_b128 per lane and row, two wave fences, a workgroup barrier in front) to form 16-byte stores.
+// Same box: the 3x3 launches with 128 or 256 output channels per pixel -2...-3 %, upconv1.0 +-0, forward +0.9...+1.4 %
+// (profiles/r04_ab_f16_epilogue_layouts.txt).  NPIX = 32: a full row; NPIX = 16: the pooled row (pixels 8 pg + {1,0,4,5}[kg] + 2r,
+// r = 0..1).  value(pg, cg, r) yields the finished fp32 element, rounded to half once, here.
+//   non-temporal: the activations a launch writes (1 GB) are not read again before they have left the L2 anyway, but as ordinary
+//   stores they displace the input tiles that neighbouring workgroups are about to share (96 walkers x 44 KB of halo tile per XCD
+//   against 4 MB of L2): same box, every 3x3 launch -2...-6 %, head -5 % (profiles/r03_nt_stores.txt).  NOT for stores that rely on
+//   the L2 to merge partial lines (k_convt_t16: +50 %); here every line is written whole by one instruction.
 template <int NPIX, typename V>
-__device__ __forceinline__ void h16_store_row(float* stg, int lane, V value, _Float16* base, int stride, int xlim, bool rowok, bool full) {
+__device__ __forceinline__ void h16_store_row(int lane, V value, _Float16* base, int stride, int xlim, bool rowok, bool full) {
     constexpr int per = NPIX == 32 ? 4 : 2;
-    const int c16 = lane & 15, pb = (0xa802 >> (4 * (lane >> 4))) & 15;
+    const int c16 = lane & 15, kg = lane >> 4;
+    _Float16* const lane_base = base + 4 * c16;
 #pragma unroll
     for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-            for (int r = 0; r < per; ++r)
-                stg[((NPIX / 2) * pg + (NPIX == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r)) * WS_STRIDE + cg * 16 + c16] = value(pg, cg, r);
-    wave_lds_fence();
-    for (int it = 0; it < NPIX / 8; ++it) {
-        const int px = it * 8 + (lane >> 3);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + px * WS_STRIDE + (lane & 7) * 8 + 4);
-        f16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
-        // non-temporal: eight lanes write a pixel's whole 128-byte line, and the activations a launch writes (1 GB) are not read again
-        // before they have left the L2 anyway — but as ordinary stores they displace the input tiles that neighbouring workgroups are
-        // about to share (96 walkers x 44 KB of halo tile per XCD against 4 MB of L2).  Same box: every 3x3 launch -2...-6 %, head -5 %
-        // (profiles/r03_nt_stores.txt).  NOT for stores that rely on the L2 to merge partial lines (k_convt_t16: +50 %).
-        if (full || (rowok && px < xlim)) __builtin_nontemporal_store(v, reinterpret_cast<f16x8*>(base + (size_t)px * stride + (lane & 7) * 8));
-    }
-    wave_lds_fence();
+        for (int r = 0; r < per; ++r) {
+            const int pb = (0xa802 >> (4 * kg)) & 15;
+            const int px = (NPIX / 2) * pg + (NPIX == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r);
+            const f16x4 v = {(_Float16)value(pg, 0, r), (_Float16)value(pg, 1, r), (_Float16)value(pg, 2, r), (_Float16)value(pg, 3, r)};
+            if (full || (rowok && px < xlim)) __builtin_nontemporal_store(v, reinterpret_cast<f16x4*>(lane_base + (size_t)px * stride));
+        }
 }
 
 // Epilogue of k_conv3x3_h16: bias + ReLU on the wave's two rows (+ the 2x2 max-pooled copy).
 template <int COUT, int MODE, typename Args>
-__device__ __forceinline__ void h16_epilogue(const Args& a, float* stg, f32x4 (&acc)[2][2][4], const float (&bias_v)[4], int n, int y0, int x0,
+__device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0,
                                              int wave, int lane, int cobase) {
     const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int y = y0 + 2 * wave + m;
         _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0) * a.out_ps + a.out_coff + cobase;
-        h16_store_row<32>(stg, lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
+        h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
     }
     if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
         const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
         const int py = (y0 >> 1) + wave;
         _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp + (x0 >> 1)) * COUT + cobase;
-        h16_store_row<16>(stg, lane,
+        h16_store_row<16>(lane,
                           [&](int pg, int cg, int r) {
                               const float v = fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1]));
                               return fmaxf(v + bias_v[cg], 0.f);
@@ -265,8 +262,14 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, float* stg, f32x4 (&
 //   * wave tile = 4 pixel groups (2 rows x 2 halves of 16) x 4 channel groups of 16 -> 16 accumulator tiles of 4 registers;
 //     per tap: 4 A + 4 B fragments (ds_read_b128 each), 16 MFMAs;
 //   * A: lane (pixel = l & 15, k-group = l >> 4) takes channels 8kg..8kg+7 -> the halo tile lies in LDS as four planes
-//     [k-group][352 pixel slots] of 16-byte quads: the 16 lanes of a ds_read_b128 service group are 16 consecutive pixels of one
-//     or two planes whose stride is a multiple of 16 slots -> conflict-free, every (tap, row, half) address an immediate;
+//     [k-group][340 pixel slots] of 16-byte quads.  A ds_read_b128 is served in groups of 16 lanes — {0-3,12-15} of one k-group with
+//     {4-11} of the next (MI355X_MICROARCH.md, LDS): with planes 340 = 4 (mod 16) slots apart and the MFMA rows permuted (h16_prow)
+//     those cover 16 different slots (mod 16): every fragment READ is conflict-free, every (tap, row, half) address an immediate.
+//     The halo WRITES (ds_write_b128, served 8 lanes at a time: two pixels x four k-groups) are 2-way conflicted by construction, which is
+//     most of the 18-29 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE these launches show.  Round 4 measured the conflict-free alternatives
+//     (profiles/r04_ab_f16_epilogue_layouts.txt): 8 lanes on 8 different slots (mod 8) means the four lanes of a load quad fetch from
+//     different pixels instead of one pixel's 64 contiguous bytes — 8 consecutive pixels of a k-group per 8 lanes: 3x3 launches +3...4 %;
+//     lane pairs of 32 bytes: +1...3 %; planes of 352 slots with the round-3 quads (writes 4-way): +1.5 %.  Coalesced loads win;
 //   * B: packed on the host per lane, [chunk][dx][dy][channel group][lane = 16 kg + col][8] (cid_api.hip packed_index_h16);
 //     one tap column (12 KiB) at a time by LDS-DMA into one of two buffers — no staging registers, and the LDS stays under a
 //     third of the CU's; the halo tile of the next chunk waits in 24 registers over the chunk's last sub-step;
@@ -282,17 +285,15 @@ template <int CIN, int COUT, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
-    constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see below
+    constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see above
     static_assert(PLANE % 16 == 4, "the fragment row permutation below assumes plane stride = 4 mod 16");
     constexpr int NSLOT = LPIX * 4, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6
     constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * 3;
     constexpr int NB = COUT / NTILE;
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     constexpr int HALO_SLOTS = 4 * PLANE;
-    // LDS: [B buffer 0][B buffer 1][halo planes]; the epilogue's store staging (4 waves x WS_FLOATS floats) takes the END of it and
-    // must leave B buffer 0 alone: the next item's first B sub-chunk lands there while the epilogue runs
-    constexpr int STAGE_SLOTS = (4 * WS_FLOATS * 4 + 15) / 16;
-    constexpr int LDS_SLOTS = (BSUB + STAGE_SLOTS > 2 * BSUB + HALO_SLOTS) ? BSUB + STAGE_SLOTS : 2 * BSUB + HALO_SLOTS;   // 47.0 KiB -> three workgroups per CU
+    // LDS: [B buffer 0][B buffer 1][halo planes]: 46.0 KiB -> three workgroups per CU (the epilogue stores from registers, round 4)
+    constexpr int LDS_SLOTS = 2 * BSUB + HALO_SLOTS;
     constexpr int HB = 2 * BSUB;                                          // first halo slot
     static_assert(NSUB % 2 == 0, "the last sub-step must read B buffer 1");
     __shared__ f32x4 lds[LDS_SLOTS];
@@ -458,9 +459,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         wbase = nb * NSUB * (BSUB * 16) + zs;
         const int cobase = nb * NTILE;
-        float bias_v[4];
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg) bias_v[cg] = a.bias[cobase + cg * 16 + c16 + zs];
+        const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + cobase + 4 * c16 + zs);   // column c16 of group cg = channel 4 c16 + cg
 #ifdef H16_TRACE
         if (tid == 0 && first_item) trace[1] = __builtin_readcyclecounter();
 #endif
@@ -482,11 +481,10 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
         if (tid == 0 && first_item) trace[2] = __builtin_readcyclecounter();
 #endif
-        __syncthreads();   // the store staging reuses the halo planes and B buffer 1
-        {
+        {   // no barrier: the epilogue touches no LDS (round 4), so a wave stores while its siblings finish their MFMAs
             int lane_e;    // opaque copy of the lane id: keeps the epilogue's address arithmetic out of the item loop's registers
             asm volatile("v_mov_b32 %0, %1" : "=v"(lane_e) : "v"(tid & 63));
-            h16_epilogue<COUT, MODE>(a, reinterpret_cast<float*>(lds + (LDS_SLOTS - STAGE_SLOTS)) + wave * WS_FLOATS, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
+            h16_epilogue<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
         }
 #ifdef H16_TRACE
         if (tid == 0 && first_item) {
@@ -504,7 +502,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         // ---- item boundary: the prefetched item becomes the current one ----
         n = n2; y0 = y02; x0 = x02; local = local2; nb = nb2;
         rsrc_in = image_rsrc(n);
-        __syncthreads();   // every wave has left the staging area: the halo planes may be written again
+        __syncthreads();   // every wave has read its last fragments of this item: the halo planes may be written again
         halo_to_lds();     // its loads are younger than the B DMA issued with them: their arrival vouches for B buffer 0 as well
         decode_next();
         __syncthreads();
@@ -520,17 +518,16 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 //   * input: planar [3][10][36] halfs in LDS, filled like k_conv_head's (all loads of the NEXT tile in flight under this tile's work);
 //   * A: lane (pixel h16_prow(lane & 15), k-group kg) gathers its eight k = 8kg..8kg+7 with eight 2-byte LDS reads at lane-constant offsets;
 //   * B: [4 channel groups][lane][8] halfs, 16 registers for the whole kernel (host: pack_head_h16);
-//   * stores: h16_store_row (bias, ReLU, wave-private staging, 16-byte stores), one output row at a time.
+//   * stores: h16_store_row (bias, ReLU, 8-byte stores straight from the accumulators: whole 128-byte lines), one output row at a time.
 template <bool IN_U8>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) {
     constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;
     constexpr int IMG_BYTES = (3 * PLANE * 2 + 15) / 16 * 16;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[IMG_BYTES + 4 * WS_FLOATS * 4];   // image | store staging (37.0 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[IMG_BYTES];   // the planar half image (2.1 KB)
     _Float16* const img_h = reinterpret_cast<_Float16*>(lds_raw);
     int grp, nb;
     if (!decode_block(a.groups_total, a.groups_per_xcd, 1, grp, nb)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, kg = lane >> 4;
-    float* const stg = reinterpret_cast<float*>(lds_raw + IMG_BYTES) + wave * WS_FLOATS;
 
     constexpr int NS = 3 * LH * 34, NIT = (NS + THREADS - 1) / THREADS;
     const size_t img = (size_t)a.src.H * a.src.W * 3;   // elements per image in either input format
@@ -577,12 +574,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
     int n, y0, x0;
     request_tile(tile0, n, y0, x0);
     f16x8 bfr[4];
-    float bias_v[4];
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) {
-        bfr[cg] = reinterpret_cast<const f16x8*>(a.w)[cg * 64 + lane];
-        bias_v[cg] = a.bias[cg * 16 + c16];
-    }
+    for (int cg = 0; cg < 4; ++cg) bfr[cg] = reinterpret_cast<const f16x8*>(a.w)[cg * 64 + lane];
+    const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + 4 * c16);   // column c16 of group cg = channel 4 c16 + cg
     int koff[8];   // k = 8 kg + e = 3 tap + c -> offset of (plane c, tap row, tap column); k >= 27 meets zero weights, any finite element will do
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -617,7 +611,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
             }
             const int y = y0 + 2 * wave + m;
             _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W + x0) * 64;
-            h16_store_row<32>(stg, lane, [&](int pg, int cg, int r) { return fmaxf(acc[pg][cg][r] + bias_v[cg], 0.f); }, orow, 64, a.W - x0, y < a.H, full);
+            h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[pg][cg][r] + bias_v[cg], 0.f); }, orow, 64, a.W - x0, y < a.H, full);
         }
         n = nn; y0 = ny0; x0 = nx0;
         if (t + 1 < ntile) __syncthreads();   // every wave is done reading the planes before the next tile overwrites them

@@ -18,8 +18,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH >
 echo "stats pass done"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_sq" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $SHORT > "$OUT/bench_pmc_sq.json" 2> "$OUT/pmc_sq.err" || { echo "pmc sq pass failed"; tail -5 "$OUT/pmc_sq.err"; exit 1; }
 echo "pmc sq pass done"
+# ALU accounting: how many vector instructions are issued beside the MFMAs.  The fp32 MFMA runs at the vector
+# rate on the SIMD's ALUs, so (MFMA busy cycles + VALU issue cycles) / SIMD cycles is the ceiling argument of DESIGN.md section 2.
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_alu" --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 -- $SHORT > "$OUT/bench_pmc_alu.json" 2> "$OUT/pmc_alu.err" || { echo "pmc alu pass failed"; tail -5 "$OUT/pmc_alu.err"; exit 1; }
+echo "pmc alu pass done"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_fetch" --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- $SHORT > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { echo "pmc fetch pass failed"; tail -5 "$OUT/pmc_fetch.err"; exit 1; }
 echo "pmc fetch pass done"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_write" --pmc WRITE_SIZE -- $SHORT > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" || { echo "pmc write pass failed"; tail -5 "$OUT/pmc_write.err"; exit 1; }
 echo "pmc write pass done"
+# optional diagnostic pass: EXTRA_PMC="<counters>" (e.g. the LDS set: SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
+# SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL) -> $OUT/pmc_extra
+if [ -n "$EXTRA_PMC" ]; then
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_extra" --pmc $EXTRA_PMC -- $SHORT > "$OUT/bench_pmc_extra.json" 2> "$OUT/pmc_extra.err" || { echo "pmc extra pass failed"; tail -5 "$OUT/pmc_extra.err"; exit 1; }
+  echo "pmc extra pass done"
+fi
 find "$OUT" -name "*.csv" | head -40

@@ -79,6 +79,33 @@ def main():
             if missing:
                 sys.exit(f"summarize.py: the {label} lacks default-forward kernels {missing}: this is not a profile of the default build "
                          f"(kernels found: {sorted(table)}); use --allow-other-kernels for a non-default configuration")
+    # ---- ALU accounting (pass pmc_alu; optional for profiles collected before round 4) ----
+    # SQ_INSTS_VALU counts every vector-ALU instruction INCLUDING the MFMAs (k_conv_tail_z, which has no MFMA, and the per-layer
+    # differences agree with the static count: ~38 plain VALU per 48-MFMA unit + ~510 per item in k_wino42_conv), so the plain vector
+    # instructions are the difference.  One of them holds the
+    # SIMD's ALU for VALU_ISSUE_CYCLES when it runs beside an fp32 MFMA stream (wave64 on a SIMD-32: 2 passes x 2 cycles = 4 nominal;
+    # tools/mix_bench measured 2.8 cycles of matrix-pipe time per instruction in round 1: both are printed).  SQ_VALU_MFMA_BUSY_CYCLES is
+    # in cycles summed over the SIMDs; SQ_BUSY_CYCLES x 32 = SIMD cycles (see below).
+    alu, alu_lines = {}, []
+    if os.path.isdir(os.path.join(src, "pmc_alu")):
+        al, _ = load_counters(os.path.join(src, "pmc_alu"))
+        alu_lines = ["", "ALU accounting (separate pass): plain VALU = SQ_INSTS_VALU - SQ_INSTS_MFMA; alu_frac = (MFMA busy cycles + plain VALU x c) / SIMD cycles",
+                     "", "| kernel | MFMA insts | plain VALU insts | VALU per MFMA | MFMA busy % | alu_frac (c = 4) | alu_frac (c = 2.8) | ACTIVE_INST_VALU % of SIMD cycles | MFMA+VALU co-exec % of MFMA busy | MFMA MOPS F32 / F16 |",
+                     "|---|---|---|---|---|---|---|---|---|---|"]
+        for k in sorted(avg_ns, key=lambda k: -avg_ns[k]):
+            c = al.get(k)
+            if not c or not k.startswith("k_"):
+                continue
+            simd = c.get("SQ_BUSY_CYCLES", float("nan")) * 32.0
+            mf, va = c.get("SQ_INSTS_MFMA", 0.0), c.get("SQ_INSTS_VALU", 0.0)
+            plain = va - mf
+            busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan"))
+            f4, f28 = (busy + 4.0 * plain) / simd, (busy + 2.8 * plain) / simd
+            alu[k] = {"mfma_busy_frac": busy / simd, "alu_frac": f4, "alu_frac_c2p8": f28, "valu_per_mfma": plain / mf if mf else None,
+                      "insts_mfma": mf, "insts_valu_plain": plain}
+            alu_lines.append(f"| `{k}` | {mf:.4g} | {plain:.4g} | {plain / mf if mf else float('nan'):.2f} | {100 * busy / simd:.1f} | {f4:.3f} | {f28:.3f} | "
+                             f"{100 * 4 * c.get('SQ_ACTIVE_INST_VALU', float('nan')) / simd:.1f} | {100 * c.get('SQ_VALU_MFMA_COEXEC_CYCLES', float('nan')) / busy if busy else float('nan'):.1f} | "
+                             f"{c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0):.3g} / {c.get('SQ_INSTS_VALU_MFMA_MOPS_F16', 0):.3g} |")
     traffic = {}
     lines = ["| kernel | avg ms (stats pass) | HBM read MB (2xFETCH) | HBM write MB | MFMA busy % of SIMD cycles | WAIT_ANY % | WAIT_INST_ANY % | ACTIVE_INST % | LDS conflict % of LDS active | eff. clock GHz |",
              "|---|---|---|---|---|---|---|---|---|---|"]
@@ -101,10 +128,15 @@ def main():
         lds = 100.0 * c.get("SQ_LDS_BANK_CONFLICT", float("nan")) / c.get("SQ_LDS_IDX_ACTIVE", float("nan")) if c.get("SQ_LDS_IDX_ACTIVE") else float("nan")
         lines.append(f"| `{k}` | {avg_ns[k] / 1e6:.4f} | {rd / 1e6:.1f} | {wrb / 1e6:.1f} | {100.0 * mfma / busy if busy else float('nan'):.1f} (raw {mfma:.3g}/{busy:.3g}) | "
                      f"{pct('SQ_WAIT_ANY'):.1f} | {pct('SQ_WAIT_INST_ANY'):.1f} | {pct('SQ_ACTIVE_INST_ANY'):.1f} | {lds:.2f} | {clk:.2f} |")
+    lines += alu_lines
     open(dst + "_pmc.md", "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(dst + "_pmc_traffic.json", "w"), indent=1)
-    if not allow_other:   # the file bench.py reads: only ever a profile of the default forward
+    if alu:
+        json.dump(alu, open(dst + "_pmc_alu.json", "w"), indent=1)
+    if not allow_other:   # the files bench.py reads: only ever a profile of the default forward
         json.dump(traffic, open(os.path.join(os.path.dirname(dst) or ".", "pmc_traffic.json"), "w"), indent=1)
+        if alu:
+            json.dump(alu, open(os.path.join(os.path.dirname(dst) or ".", "pmc_alu.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
