@@ -40,9 +40,9 @@ const char* kKernelNames[NL] = {
 };
 
 const char* kHalfKernelNames[NL] = {
-    "k_conv_head_h16", "k_conv3x3_h16<64, 64, 1>", "k_conv3x3_h16<64, 128, 0>", "k_conv3x3_h16<128, 128, 1>",
-    "k_conv3x3_h16<128, 256, 0>", "k_conv3x3_h16<256, 256, 0>", "k_convt_t16<256, 128>", "k_conv3x3_h16<256, 128, 0>",
-    "k_conv3x3_h16<128, 128, 0>", "k_convt_t16<128, 64>", "k_conv3x3_h16<128, 64, 0>", "k_conv_tail_h",
+    "k_conv_head_h16", "k_conv3x3_h16<64, 64, 1,", "k_conv3x3_h16<64, 128, 0,", "k_conv3x3_h16<128, 128, 1,",
+    "k_conv3x3_h16<128, 256, 0,", "k_conv3x3_h16<256, 256, 0,", "k_convt_t16<256, 128>", "k_conv3x3_h16<256, 128, 0,",
+    "k_conv3x3_h16<128, 128, 0,", "k_convt_t16<128, 64>", "k_conv3x3_h16<128, 64, 0, false>", "k_conv_tail_h<",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -72,7 +72,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -101,6 +101,7 @@ struct BlobLayout {
         }
         tab42_off[0] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);   // its LDS slot tables, TC = 8 and 4
         tab42_off[1] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
+        hz_off = o; o = align_up(o + 3 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused last layer: upconv1[2] as A fragments [3 row tiles][2 k-steps][64 lanes][8] halfs
         total = o;
     }
 };
@@ -293,8 +294,11 @@ struct cid_handle_s {
 
 namespace {
 
-// The fused form needs the Winograd kernel of upconv1[0] (its epilogue does the contraction) and fp32 storage.
-bool fused_tail_active(cid_handle_t h) { return h->tail_algo == CID_TAIL_FUSED && h->algo != CID_ALGO_DIRECT && h->dtype == CID_DTYPE_F32; }
+// The fused form lives in the epilogue of upconv1[0]'s kernel: the Winograd kernels on the fp32 path (not the 9-tap direct one), k_conv3x3_h16 on the
+// fp16-storage path (one 3x3 algorithm there, so always).
+bool fused_tail_active(cid_handle_t h) {
+    return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || h->algo != CID_ALGO_DIRECT);
+}
 
 int fail(cid_handle_t h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -411,6 +415,16 @@ hipError_t launch_tail_z(hipStream_t s, const float* z, const float* bias, void*
     return hipGetLastError();
 }
 
+hipError_t launch_tail_zh(hipStream_t s, const void* z, const float* bias, void* out, const Window& crop, int N, int H, int W, bool u8) {
+    TailZArgs a;
+    a.z = static_cast<const float*>(z); a.bias = bias; a.out = out; a.crop = crop; a.N = N; a.H = H; a.W = W;
+    a.blocks_per_image = cdiv(H * W, THREADS);
+    a.rcp_w = tile_rcp((unsigned)W); a.rcp_blocks = tile_rcp((unsigned)a.blocks_per_image);
+    if (u8) hipLaunchKernelGGL((k_conv_tail_zh<true>), dim3(N * a.blocks_per_image), dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_tail_zh<false>), dim3(N * a.blocks_per_image), dim3(THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 // Grid of a k_wino42_conv launch over `tiles_per_xcd` tiles per XCD group and NB column blocks.  Small launches: one workgroup
 // per (tile, column block), a.walk = 0.  Once there are more items than the chip holds at a time — two workgroups per CU (LDS
 // 75 KiB, <= 256 VGPRs) — the grid is what is resident and the workgroups WALK: a.walk = grid / 8 walkers per XCD group, each
@@ -487,7 +501,7 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
     return Wc > 32 ? launch_wino64_tc<CIN, COUT, MODE == 1, 32>(s, a) : launch_wino64_tc<CIN, COUT, MODE == 1, 16>(s, a);
 }
 
-template <int CIN, int COUT, int MODE>
+template <int CIN, int COUT, int MODE, bool ZOUT = false>
 hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void* in, int Hin, int Win, int in_ps,
                          void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N);
 
@@ -537,13 +551,14 @@ hipError_t launch_tail2(hipStream_t s, const Tail2Args& a, bool u8) {
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int MODE>
+template <int CIN, int COUT, int MODE, bool ZOUT>
 hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void* in, int Hin, int Win, int in_ps,
                          void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N) {
     GemmConvArgsH a;
     a.in = static_cast<const _Float16*>(in); a.w = reinterpret_cast<const _Float16*>(blob + kBlob.h_off[layer]);
     a.bias = blob + kBlob.b_off[layer];
     a.out = static_cast<_Float16*>(out); a.pool = static_cast<_Float16*>(pool);
+    if (ZOUT) a.pool = const_cast<_Float16*>(reinterpret_cast<const _Float16*>(blob + kBlob.hz_off));   // ZOUT: `out` = the z planes, `pool` = the last layer's weights (read only)
     a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps;
     a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
     const TileGrid g = tiles_for(N, Hc, Wc);
@@ -551,14 +566,14 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
     constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;
     a.walk = 0;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 && !ZOUT) {
         // streaming form: persistent workgroups (two waves per SIMD: 2 per CU of four waves, 1 of eight) over runs of TP input pixels
         using CG = ConvTGeom<CIN, COUT>;
         a.tiles_x = (Hin * Win + CG::TP - 1) / CG::TP; a.tiles_total = N * a.tiles_x;
         a.rcp_x = tile_rcp(a.tiles_x); a.rcp_xy = tile_rcp(Win);
         const int wgs = device_cus() * 2 / CG::CB;
         hipLaunchKernelGGL((k_convt_t16<CIN, COUT>), dim3(a.tiles_total < wgs ? a.tiles_total : wgs), dim3(64 * CG::NW), 0, s, a);
-    } else {
+    } else if constexpr (MODE != 2) {
         // walking workgroups (conv_kernels_f16.h): three per CU (47 KiB of LDS, <= 168 VGPRs) once there are more items than that —
         // on the layers with CIN <= 128, where an item is short beside its prologue (same-box: down1.2 -15 %, down2.0 -11 %, the
         // CIN = 128 layers -0.3...-1.5 %).  With CIN = 256 walking LOSES 3-5 %: a tile's NB column blocks then run one after the
@@ -567,7 +582,7 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
         if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
-        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE>), dim3(grid), dim3(THREADS), 0, s, a);
+        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();
 }
@@ -636,7 +651,11 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     STEP((launch_layer<128, 64, 2>(h, s, blob, 9, B[D2], d.Hu2, d.Wu2, 128, B[CAT1], 128, 0, d.Hu2, d.Wu2, d.Hu2, d.Wu2, nullptr, N)));
     const bool fused_tail = fused_tail_active(h);
     const Window crop = crop_win ? *crop_win : Window{0, 0, d.Hu1, d.Wu1};
-    if (fused_tail) {
+    if (fused_tail && h->dtype == CID_DTYPE_F16) {
+        // the same on the fp16-storage path: z[N][9][Hu1][Wu1][4] halfs into the t4 region                         app.py:75-77
+        STEP((launch_gemm_h<128, 64, 0, true>(s, blob, 10, B[CAT1], d.Hu1, d.Wu1, 128, B[T4], 64, 0, d.Hu1, d.Wu1, d.Hu1, d.Wu1, nullptr, N)));
+        STEP(launch_tail_zh(s, B[T4], blob + kBlob.b_off[11], out, crop, N, d.Hu1, d.Wu1, out_fmt == CID_FMT_U8_NHWC));
+    } else if (fused_tail) {
         // upconv1[0] + ReLU, with upconv1[2]'s channel contraction in its epilogue: z planes into the t4 region     app.py:75-77
         STEP(launch_upconv1_0_z(h->algo, s, blob, B[CAT1], d.Hu1, d.Wu1, B[T4], N));
         // the nine-tap shifted sum + bias + tanh, -> NCHW out                              app.py:77,103
@@ -726,6 +745,14 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
                 const int col = (kh * 3 + kw) * 3 + co, s = ci >> 4, hh = (ci >> 3) & 1, e = ci & 7;
                 hd[((size_t)s * 64 + hh * 32 + col) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
+            });
+            // and for the fused form (h16_zout_epilogue): the A operand of z^T = W2' . X^T on v_mfma_f32_16x16x32_f16, row 4 tap + co
+            // (co = 3 and rows 36..47 stay zero): [row tile t][k-step ks][lane = 16 kga + row][e] with ci = 32 ks + 8 kga + e
+            _Float16* hz = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.hz_off);
+            std::memset(hz, 0, 3 * 2 * 64 * 8 * sizeof(_Float16));
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                const int row = 4 * (kh * 3 + kw) + co, t = row >> 4, ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
+                hz[(((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
         }
         if (L.kind == CONV || L.kind == CONVT) {
@@ -940,7 +967,10 @@ int cid_forward_timed(cid_handle_t h, const float* in, float* out, int N, int H,
 const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name : nullptr; }
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
-    if (h && h->dtype == CID_DTYPE_F16) return kHalfKernelNames[i];
+    if (h && h->dtype == CID_DTYPE_F16) {
+        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true>" : "k_conv_tail_zh<";
+        return kHalfKernelNames[i];
+    }
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];
     if (h && h->algo != CID_ALGO_DIRECT && kWino64KernelNames[i]) return kWino64KernelNames[i];
     return kKernelNames[i];
@@ -1136,12 +1166,15 @@ int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops
     const double px = (double)N * d.Hu1 * d.Wu1;
     double f11, b11;
     cid_launch_work(11, N, H, W, &f11, &b11);
+    // z elements per pixel: 27 fp32 planes; on the fp16-storage path 9 taps x 4 halfs (three channels and a pad), counted here in
+    // fp32-sized elements like every other activation of that path (bench.py halves the bytes between the first and the last tensor)
+    const double zc = h->dtype == CID_DTYPE_F16 ? 36 : 27;
     if (i == 10) {
         *flops += f11;
-        *bytes += 4.0 * px * (27 - 64) + 4.0 * ref_weight_count(kLayers[11]);
+        *bytes += 4.0 * px * (zc - 64) + 4.0 * ref_weight_count(kLayers[11]);
     } else {
         *flops = 0.0;
-        *bytes = 4.0 * (px * (27 + 3) + 3);
+        *bytes = 4.0 * (px * (zc + 3) + 3);
     }
     return CID_OK;
 }

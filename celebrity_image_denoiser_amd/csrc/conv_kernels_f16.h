@@ -31,6 +31,9 @@ struct GemmConvArgsH {
     int tiles_x, tiles_y, tiles_total, tiles_per_xcd;
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
     int walk;                 // k_conv3x3_h16: 0 = one (tile, column block) per workgroup; > 0 = tile walkers per XCD group (gridDim.x / 8)
+    // k_conv3x3_h16<.., ZOUT> re-uses two fields instead of growing the struct (every kernel argument costs SGPRs, and these kernels sit at
+    // the SGPR limit: two more pointers spilled 4 VGPRs in every variant): `out` = z[N][9 taps][Hs][Ws][4] halfs (co 0..2, one pad),
+    // `pool` = upconv1[2]'s weights as A fragments, [3 row tiles][2 k-steps][64 lanes][8] halfs (cid_api.hip, hz_off)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -212,19 +215,24 @@ __device__ __forceinline__ int h16_prow(int i) { return ((0xa802 >> (4 * (i >> 2
 //   stores they displace the input tiles that neighbouring workgroups are about to share (96 walkers x 44 KB of halo tile per XCD
 //   against 4 MB of L2): same box, every 3x3 launch -2...-6 %, head -5 % (profiles/r03_nt_stores.txt).  NOT for stores that rely on
 //   the L2 to merge partial lines (k_convt_t16: +50 %); here every line is written whole by one instruction.
+//   Addressing: raw buffer stores over ONE image (`rsrc`), a per-lane byte offset that holds for the whole row (the lane's first pixel
+//   and channel quad) plus a scalar offset per (pixel group, register) — one VGPR of address instead of a 64-bit pointer per store
+//   (these kernels sit at the 168-register step).  `row_off` = byte offset of the row's pixel 0, channel 0 of the column block (scalar).
 template <int NPIX, typename V>
-__device__ __forceinline__ void h16_store_row(int lane, V value, _Float16* base, int stride, int xlim, bool rowok, bool full) {
+__device__ __forceinline__ void h16_store_row(int lane, V value, const __amdgpu_buffer_rsrc_t& rsrc, unsigned row_off, int stride, int xlim, bool rowok, bool full) {
     constexpr int per = NPIX == 32 ? 4 : 2;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int c16 = lane & 15, kg = lane >> 4;
-    _Float16* const lane_base = base + 4 * c16;
+    const int pb = (0xa802 >> (4 * kg)) & 15, p0 = NPIX == 32 ? pb : pb >> 1;            // the lane's first pixel of a 16 (8)-pixel group
+    const unsigned lane_off = (unsigned)((p0 * stride + 4 * c16) * 2);
 #pragma unroll
     for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
         for (int r = 0; r < per; ++r) {
-            const int pb = (0xa802 >> (4 * kg)) & 15;
-            const int px = (NPIX / 2) * pg + (NPIX == 32 ? pb + (r & 1) + 4 * (r >> 1) : (pb >> 1) + 2 * r);
+            const int dp = (NPIX / 2) * pg + (NPIX == 32 ? (r & 1) + 4 * (r >> 1) : 2 * r);   // compile-time
             const f16x4 v = {(_Float16)value(pg, 0, r), (_Float16)value(pg, 1, r), (_Float16)value(pg, 2, r), (_Float16)value(pg, 3, r)};
-            if (full || (rowok && px < xlim)) __builtin_nontemporal_store(v, reinterpret_cast<f16x4*>(lane_base + (size_t)px * stride));
+            const unsigned vo = (full || (rowok && p0 + dp < xlim)) ? lane_off : 0x7ffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, vo, row_off + (unsigned)(dp * stride * 2), /*nt*/ 2);
         }
 }
 
@@ -233,23 +241,92 @@ template <int COUT, int MODE, typename Args>
 __device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0,
                                              int wave, int lane, int cobase) {
     const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
+    auto image_out = [&](_Float16* base, size_t elems) {   // descriptor over image n of a tensor with `elems` halfs per image (< 2^30: cid_api.hip shape_error)
+        const unsigned long long p = (unsigned long long)(base + (size_t)n * elems);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)(elems * 2), 0x00020000);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t ro = image_out(a.out, (size_t)a.Hs * a.Ws * a.out_ps);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int y = y0 + 2 * wave + m;
-        _Float16* orow = a.out + ((size_t)(n * a.Hs + y) * a.Ws + x0) * a.out_ps + a.out_coff + cobase;
-        h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, orow, a.out_ps, a.Ws - x0, y < a.Hs, full);
+        for (int m = 0; m < 2; ++m) {
+            const int y = __builtin_amdgcn_readfirstlane(y0 + 2 * wave + m);
+            const unsigned row_off = (unsigned)(((y * a.Ws + x0) * a.out_ps + a.out_coff + cobase) * 2);
+            h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, ro, row_off, a.out_ps, a.Ws - x0, y < a.Hs, full);
+        }
     }
     if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
         const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
-        const int py = (y0 >> 1) + wave;
-        _Float16* prow = a.pool + ((size_t)(n * Hp + py) * Wp + (x0 >> 1)) * COUT + cobase;
+        const int py = __builtin_amdgcn_readfirstlane((y0 >> 1) + wave);
+        const __amdgpu_buffer_rsrc_t rp = image_out(a.pool, (size_t)Hp * Wp * COUT);
+        const unsigned prow_off = (unsigned)(((py * Wp + (x0 >> 1)) * COUT + cobase) * 2);
         h16_store_row<16>(lane,
                           [&](int pg, int cg, int r) {
                               const float v = fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1]));
                               return fmaxf(v + bias_v[cg], 0.f);
                           },
-                          prow, COUT, Wp - (x0 >> 1), py < Hp, false);
+                          rp, prow_off, COUT, Wp - (x0 >> 1), py < Hp, false);
     }
+}
+
+// ZOUT epilogue of k_conv3x3_h16<128, 64> (round 4): upconv1[0] as the producer of the last layer's input.  What the fp32 path does since
+// round 2 (wino42_kernels.h, ZOUT): upconv1[2] = Conv2d(64, 3, 3, padding=1) (app.py:77) is a 1x1 contraction per tap followed by a
+// nine-tap shifted sum, and the contraction has no halo — so it runs HERE, on the wave's finished 2 rows x 32 pixels x 64 channels, and
+// the 64-channel tensor (128 B per pixel written, then re-read with a 10x34 / 8x32 halo by k_conv_tail_h) never exists:
+//     z[n][tap][y][x][co] = sum_ci half(relu(upconv1.0))[n][y][x][ci] * W2[co][ci][tap]            72 B per pixel (9 taps x 4 halfs: co 0..2, one pad)
+// The activation is rounded to half exactly as the stored tensor was, so only z's own rounding to half is new (CPU emulation of the
+// whole path, He-gain weights, 16 images: 3.2e-3 against 3.4e-3 unfused, z half vs unfused 8.9e-4; tools/emulate_f16_zout.py).
+//   * the wave's pixels go to a wave-private LDS area [row][pixel][8 slots of 8 channels], slot XOR (pixel & 7): a lane's four
+//     consecutive channels are one ds_write_b64 (16 lanes = one pixel's 128 B: conflict-free), and the B operand of the z product —
+//     lane (column = pixel, k-group) = 8 consecutive channels — one ds_read_b128 (conflict-free by the XOR, checked exhaustively);
+//   * z^T = W2' . X^T on v_mfma_f32_16x16x32_f16 with the WEIGHTS as rows: row 4 tap + co (36 of 48 rows used: three row tiles),
+//     K = 64 channels = two steps -> 24 MFMAs per wave beside the 576 of the main loop; a lane of the result holds the four `co`
+//     of ONE (tap, pixel): 8 bytes as halfs, stored straight from registers (16 lanes = 16 consecutive pixels of a tap plane).
+template <typename Args>
+__device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0,
+                                                  int wave, int lane) {
+    const int c16 = lane & 15, kg = lane >> 4;
+    unsigned char* const stg = reinterpret_cast<unsigned char*>(stage + wave * 512);     // 2 rows x 32 pixels x 128 B
+    const int pb = (0xa802 >> (4 * kg)) & 15;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int P = 16 * pg + pb + (r & 1) + 4 * (r >> 1);
+                const f16x4 v = {(_Float16)fmaxf(acc[m][pg][0][r] + bias_v[0], 0.f), (_Float16)fmaxf(acc[m][pg][1][r] + bias_v[1], 0.f),
+                                 (_Float16)fmaxf(acc[m][pg][2][r] + bias_v[2], 0.f), (_Float16)fmaxf(acc[m][pg][3][r] + bias_v[3], 0.f)};
+                *reinterpret_cast<f16x4*>(stg + ((m * 32 + P) * 8 + ((c16 >> 1) ^ (P & 7))) * 16 + (c16 & 1) * 8) = v;
+            }
+    // the last layer's weights are requested only now, with the accumulators dead (24 registers; an L2 hit per item)
+    f16x8 wz[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wz[t][ks] = reinterpret_cast<const f16x8*>(a.pool)[(t * 2 + ks) * 64 + lane];
+    wave_lds_fence();
+    const size_t plane = (size_t)a.Hs * a.Ws;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+            const int P = 16 * pg + c16;                                                   // column of the z tile = pixel
+            f16x8 xb[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xb[ks] = *reinterpret_cast<const f16x8*>(stg + ((m * 32 + P) * 8 + ((4 * ks + kg) ^ (P & 7))) * 16);
+            const int y = y0 + 2 * wave + m, x = x0 + P;
+            const bool inside = y < a.Hs && x < a.Ws;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wz[t][0], xb[0], zero, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wz[t][1], xb[1], z, 0, 0, 0);
+                const int tap = 4 * t + kg;                                               // rows 4 kg + r of row tile t: tap 4 t + kg, co = r
+                const f16x4 hz = {(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
+                if (inside && tap < 9) *reinterpret_cast<f16x4*>(a.out + ((((size_t)n * 9 + tap) * plane + (size_t)y * a.Ws + x) << 2)) = hz;
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,9 +358,10 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4
 //     so an item's prologue (B DMA + halo request + their HBM latency, ~5-7k cycles beside 20-40k of work) is paid once per
 //     workgroup.  Everything renewed per item (B offset, halo offsets, image descriptor) is derived from per-item opaque values, or
 //     hipcc hoists it out of the item loop into registers this 168-register kernel does not have.
-template <int CIN, int COUT, int MODE>
+template <int CIN, int COUT, int MODE, bool ZOUT = false>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
+    static_assert(!ZOUT || (COUT == 64 && MODE == 0), "the fused last layer contracts the 64 channels of ONE column block");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
     constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see above
     static_assert(PLANE % 16 == 4, "the fragment row permutation below assumes plane stride = 4 mod 16");
@@ -331,11 +409,12 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             const int p = sidx >> 2, q = sidx & 3;
             const int hy = p / LW, hx = p - hy * LW;
             const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-            const bool ok = sidx < NSLOT && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+            const bool ok = p < LPIX && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
             goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
         }
     };
     const int hbase = HB + (tid & 3) * PLANE + (tid >> 2);
+    const bool halo_last = (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
     f32x4 pre[NLOAD];
     auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
 #pragma unroll
@@ -344,7 +423,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     auto halo_to_lds = [&]() {
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
-            if (it * THREADS + tid < NSLOT) lds[hbase + it * 64] = pre[it];
+            if (it + 1 < NLOAD || halo_last) lds[hbase + it * 64] = pre[it];
     };
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
@@ -484,7 +563,13 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         {   // no barrier: the epilogue touches no LDS (round 4), so a wave stores while its siblings finish their MFMAs
             int lane_e;    // opaque copy of the lane id: keeps the epilogue's address arithmetic out of the item loop's registers
             asm volatile("v_mov_b32 %0, %1" : "=v"(lane_e) : "v"(tid & 63));
-            h16_epilogue<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
+            if constexpr (ZOUT) {
+                __syncthreads();   // every wave has read its last fragments: B buffer 1 and the halo planes become the staging area (32 KiB)
+                static_assert(4 * 512 <= LDS_SLOTS - BSUB, "z staging must fit behind B buffer 0 (the next item's first B sub-chunk lands there)");
+                h16_zout_epilogue(a, lds + BSUB, acc, bias_v, n, y0, x0, wave, lane_e);
+            } else {
+                h16_epilogue<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
+            }
         }
 #ifdef H16_TRACE
         if (tid == 0 && first_item) {
@@ -595,6 +680,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
         int nn = n, ny0 = y0, nx0 = x0;
         if (t + 1 < ntile) request_tile(tile0 + t + 1, nn, ny0, nx0);   // in flight under this tile's MFMAs and stores
         const bool full = y0 + TILE_H <= a.H && x0 + TILE_W <= a.W;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<_Float16*>(a.out) + (size_t)n * a.H * a.W * 64), (short)0,
+                                                                            a.H * a.W * 128, 0x00020000);   // image n of t0: 128 B per pixel
 #pragma unroll 1
         for (int m = 0; m < 2; ++m) {   // a row at a time: 32 accumulator registers, this kernel sits at the 128-register step
             f32x4 acc[2][4];
@@ -609,9 +696,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) 
                     acc[pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[cg], zero, 0, 0, 0);
                 }
             }
-            const int y = y0 + 2 * wave + m;
-            _Float16* orow = static_cast<_Float16*>(a.out) + ((size_t)(n * a.H + y) * a.W + x0) * 64;
-            h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[pg][cg][r] + bias_v[cg], 0.f); }, orow, 64, a.W - x0, y < a.H, full);
+            const int y = __builtin_amdgcn_readfirstlane(y0 + 2 * wave + m);
+            h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[pg][cg][r] + bias_v[cg], 0.f); }, ro, (unsigned)(((y * a.W + x0) * 64) * 2), 64, a.W - x0, y < a.H, full);
         }
         n = nn; y0 = ny0; x0 = nx0;
         if (t + 1 < ntile) __syncthreads();   // every wave is done reading the planes before the next tile overwrites them
@@ -739,6 +825,54 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv_tail_h(const TailArgs a) {
         }
         __syncthreads();   // everyone is done gathering z before the next tile's pieces overwrite it
         n = nn; y0 = ny0; x0 = nx0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail of the fp16-storage path, fused form (round 4; default): k_conv3x3_h16<128, 64, 0, ZOUT> has contracted the 64 channels,
+// z[n][tap][y][x][4 halfs].  What is left of upconv1[2] + tanh (app.py:77,103) is the nine-tap shifted sum, as in k_conv_tail_z:
+//     out[n][co][y][x] = tanh(bias[co] + sum_{ty,tx} z[n][3 ty + tx][y+ty-1][x+tx-1][co])        (zero outside the image)
+// One thread per pixel, NINE 8-byte loads (a tap's three channels travel together; consecutive lanes = consecutive pixels = 512
+// contiguous bytes per wave instruction; out-of-image taps carry an out-of-range per-lane offset), fp32 sums in tap order, three
+// tanhf.  HBM-bound on 84 B per pixel (72 z + 12 out) where k_conv_tail_h moved 140 with a halo on top.
+template <bool OUT_U8>
+__global__ void __launch_bounds__(THREADS) k_conv_tail_zh(const TailZArgs a) {
+    const unsigned b = blockIdx.x;
+    const unsigned n = a.rcp_blocks ? __umulhi(b, a.rcp_blocks) : b;
+    const unsigned p = (b - n * a.blocks_per_image) * THREADS + threadIdx.x;   // pixel index inside the image
+    const size_t plane = (size_t)a.H * a.W;
+    const unsigned y = a.rcp_w ? __umulhi(p, a.rcp_w) : p, x = p - y * a.W;
+    const bool inside = p < plane;
+    // descriptor over the image's 9 tap planes of 8 bytes per pixel (<= 302 MB: H*W < 4,194,303, cid_api.hip shape_error)
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const _Float16*>(a.z) + (size_t)n * 36 * plane), (short)0,
+                                                                        (int)(plane * 72), 0x00020000);
+    float o[3] = {a.bias[0], a.bias[1], a.bias[2]};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int yy = (int)y + ty - 1, xx = (int)x + tx - 1;
+            const bool ok = inside && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((yy * a.W + xx) * 8) : 0x7ffffff0u;   // the mask lives in the per-lane offset; the tap plane is the scalar one
+            const f16x4 hv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rz, off, (int)((3 * ty + tx) * plane * 8), 0));
+#pragma unroll
+            for (int co = 0; co < 3; ++co) o[co] += (float)hv[co];
+        }
+    const int cy = (int)y - a.crop.top, cx = (int)x - a.crop.left;   // the caller's tensor
+    if (!inside || (unsigned)cy >= (unsigned)a.crop.H || (unsigned)cx >= (unsigned)a.crop.W) return;
+    const size_t oplane = (size_t)a.crop.H * a.crop.W, op_idx = (size_t)cy * a.crop.W + cx;
+    if (OUT_U8) {
+        unsigned char* op = static_cast<unsigned char*>(a.out) + ((size_t)n * oplane + op_idx) * 3;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            const float v = fminf(fmaxf(tanhf(o[co]) * 0.5f + 0.5f, 0.f), 1.f);
+            op[co] = (unsigned char)(v * 255.0f);
+        }
+    } else {
+        float* op = static_cast<float*>(a.out) + (size_t)n * 3 * oplane + op_idx;
+        op[0] = tanhf(o[0]);
+        op[oplane] = tanhf(o[1]);
+        op[2 * oplane] = tanhf(o[2]);
     }
 }
 

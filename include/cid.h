@@ -192,7 +192,7 @@ enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2, CID_ALGO_WINOGRAD42 = 3 };
  * The caller-side tensors (cid_forward / cid_forward_ex) keep their formats; only the arena and the weight
  * segments read change.  A different numerical contract from the reference's fp32 (tolerances: tests/).
  */
-enum { CID_DTYPE_F32 = 0, CID_DTYPE_F16 = 1 };
+enum { CID_DTYPE_F32 = 0, CID_DTYPE_F16 = 1 };   /* (the half path's kernels use v_mfma_f32_16x16x32_f16 since round 2) */
 int cid_set_compute_dtype(cid_handle_t h, int dtype);
 int cid_get_compute_dtype(cid_handle_t h, int* dtype);
 int cid_set_conv_algo(cid_handle_t h, int algo);
@@ -200,8 +200,9 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
 /*
  * How the last layer (upconv1[2] = Conv2d(64,3,3,p=1) + tanh, backend/app.py:77,103) runs on the fp32 path; same function:
  *   CID_TAIL_FUSED  (default) its 64 -> 27 (tap x channel) contraction runs in the epilogue of upconv1[0]'s kernel, on the
- *                   tile still in LDS; the last launch is the nine-tap shifted sum + bias + tanh over 27 planes.  Needs
- *                   a Winograd algorithm and CID_DTYPE_F32; otherwise the handle behaves as CID_TAIL_BANDS.
+ *                   tile still in LDS; the last launch is the nine-tap shifted sum + bias + tanh over 27 fp32 planes (CID_DTYPE_F32; needs
+ *                   a Winograd algorithm, with CID_ALGO_DIRECT the handle behaves as CID_TAIL_BANDS) or over 9 tap planes of 4 halfs
+ *                   (CID_DTYPE_F16, round 4).
  *   CID_TAIL_BANDS  separate kernel: a workgroup slides down a band of rows, the contraction is computed once per pixel
  *                   (images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
  *   CID_TAIL_TILES  separate kernel: 8x32-pixel tiles, the contraction is computed over each tile's halo (round 1's kernel)

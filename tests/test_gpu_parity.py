@@ -619,6 +619,20 @@ def test_fp16_storage_path(weight_sets, golden_dir, wset, tol):
     gu = np.load(os.path.join(golden_dir, f"u8_{wset}_32x40.npz"))
     yu = m.forward_u8(torch.from_numpy(gu["noisy_u8"]).to("cuda:0")).cpu().numpy().astype(np.int16)
     assert np.abs(yu - gu["out_u8"].astype(np.int16)).max() <= (1 if wset == "default" else 2)
+    # the last layer's two forms on this path: fused (default since round 4: its 64 -> 9 x 4 contraction runs in upconv1[0]'s epilogue, z
+    # rounded to half, k_conv_tail_zh sums the nine taps) and the separate tiled kernel on the stored 64-channel tensor
+    from celebrity_image_denoiser_amd.generator import launch_table
+    assert m.tail_algo == "fused"
+    names = [r[1] for r in launch_table(2, 128, 128, m)]
+    assert names[10].startswith("k_conv3x3_h16<128, 64, 0, true") and names[11].startswith("k_conv_tail_zh")
+    m.tail_algo = "tiles"
+    names = [r[1] for r in launch_table(2, 128, 128, m)]
+    assert names[10].startswith("k_conv3x3_h16<128, 64, 0, false") and names[11].startswith("k_conv_tail_h")
+    y_tiles = _run(m, x)
+    assert float(np.abs(y_tiles - g["out"]).max()) <= tol
+    assert float(np.abs(y_tiles - y).max()) <= (1e-4 if wset == "default" else 1.5e-3)     # what z's rounding to half costs (emulated: 2e-5 / 9e-4)
+    assert np.abs(_run(m, gt["x"]) - gt["out"]).max() <= tol
+    m.tail_algo = "fused"
     m.compute_dtype = "f32"
     assert np.abs(_run(m, x) - g["out"]).max() <= TOL
 
