@@ -15,6 +15,10 @@
 #pragma once
 #include "conv_kernels.h"
 
+#ifndef H16_ABLATE   // timing / energy experiments of csrc/tools/h16_trace only (wrong results when non-zero): 1 no B DMA after a workgroup's first item,
+#define H16_ABLATE 0  // 2 no halo loads after the first item, 4 no stores, 8 fragments read from LDS once per item (MFMAs on stale registers)
+#endif
+
 namespace cid {
 
 constexpr int HPS = 5;   // LDS slots (16 B) per pixel: 4 data (32 halfs) + 1 pad
@@ -231,7 +235,7 @@ __device__ __forceinline__ void h16_store_row(int lane, V value, const __amdgpu_
         for (int r = 0; r < per; ++r) {
             const int dp = (NPIX / 2) * pg + (NPIX == 32 ? (r & 1) + 4 * (r >> 1) : 2 * r);   // compile-time
             const f16x4 v = {(_Float16)value(pg, 0, r), (_Float16)value(pg, 1, r), (_Float16)value(pg, 2, r), (_Float16)value(pg, 3, r)};
-            const unsigned vo = (full || (rowok && p0 + dp < xlim)) ? lane_off : 0x7ffffff0u;
+            const unsigned vo = (!(H16_ABLATE & 4) && (full || (rowok && p0 + dp < xlim))) ? lane_off : 0x7ffffff0u;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, vo, row_off + (unsigned)(dp * stride * 2), /*nt*/ 2);
         }
 }
@@ -360,6 +364,9 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     hipcc hoists it out of the item loop into registers this 168-register kernel does not have.
 template <int CIN, int COUT, int MODE, bool ZOUT = false>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
+#ifndef CID_EXPERIMENTS
+    static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
+#endif
     static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
     static_assert(!ZOUT || (COUT == 64 && MODE == 0), "the fused last layer contracts the 64 channels of ONE column block");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
@@ -401,6 +408,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
     };
     // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot HB + (tid & 3) * PLANE + (tid >> 2) + 64 it
+    bool abl_on = false;   // H16_ABLATE: a workgroup's first item runs in full (so LDS holds real data), the ablation applies from its second
     unsigned goff[NLOAD];
     auto halo_offsets = [&](int ty0, int tx0, int lane_id) {
 #pragma unroll
@@ -417,10 +425,12 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     const bool halo_last = (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
     f32x4 pre[NLOAD];
     auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
+        if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * 64, 0));
     };
     auto halo_to_lds = [&]() {
+        if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
             if (it + 1 < NLOAD || halo_last) lds[hbase + it * 64] = pre[it];
@@ -429,6 +439,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
     const unsigned vlane = lane * 16;
     auto dma_b = [&](int wb, int g) {   // wb = byte offset of the item's column block in the packed weights
+        if ((H16_ABLATE & 1) && abl_on) return;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int soff = wb + g * (BSUB * 16) + (wave_s + 4 * j) * 1024;
@@ -455,10 +466,10 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         n2 = uni(n2); y02 = uni(y02); x02 = uni(x02); local2 = uni(local2); nb2 = uni(nb2); has_next = uni(has_next) != 0;
     };
 
-#ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 stamps s_memtime at the phase boundaries of its FIRST item into a.pool, results unchanged
+#ifdef H16_TRACE   // experiment (csrc/tools/h16_trace): thread 0 sums s_memtime over the phases of ALL its items into a.pool (MODE 0 only), results unchanged
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(a.pool) + (size_t)blockIdx.x * 8;
-    if (tid == 0) trace[0] = __builtin_readcyclecounter();
-    bool first_item = true;
+    unsigned long long tr_t0 = __builtin_readcyclecounter(), tr_last = tr_t0, tr_main = 0, tr_epi = 0, tr_bnd = 0, tr_items = 0;
+    auto tr_lap = [&](unsigned long long& acc_) { const unsigned long long t = __builtin_readcyclecounter(); acc_ += t - tr_last; tr_last = t; };
 #endif
     // ---- prologue of the workgroup's first item ----
     __amdgpu_buffer_rsrc_t rsrc_in = image_rsrc(n);
@@ -480,18 +491,42 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
     int wbase = 0, zs = 0;                                                // this item's B offset (bytes) and an opaque zero, renewed per item
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
-    auto substep = [&](auto first_tag, auto last_tag, int g, int dx) {
+    auto substep = [&](auto first_tag, auto last_tag, int g, int dx, int req_ck = -1) {
         constexpr bool FIRST = decltype(first_tag)::value;    // first sub-step of an item: the accumulators start from zero
         constexpr bool LAST = decltype(last_tag)::value;      // last one: fetch the NEXT item's first B sub-chunk and halo chunk instead
         const f16x8* bq = ldsh + (g & 1) * BSUB + lane;
         const f16x8* aq = ldsh + abase + dx;
-        if (!LAST) dma_b(wbase, g + 1);
-        else {                                                // B first: the halo loads behind it in the queue then vouch for it
+        if (!LAST) {
+            dma_b(wbase, g + 1);
+            // the NEXT chunk's halo is requested in a chunk's MIDDLE sub-step, BEHIND that sub-step's B DMA: the seam after it then
+            // waits for all but the six youngest operations (= the B DMA only), and the halo loads have two sub-steps to land instead
+            // of one (round 4; rounds 2-3 requested them in front of the last sub-step)
+            if (req_ck >= 0) request_halo(rsrc_in, req_ck, zs);
+        } else {                                                // B first: the halo loads behind it in the queue then vouch for it
             dma_b(nb2 * NSUB * (BSUB * 16) + zs, 0);
             halo_offsets(y02, x02, tid + zs);
             request_halo(image_rsrc(n2), 0, zs);
         }
         f16x8 ar[4][2], bf[3][4];
+        if ((H16_ABLATE & 8) && !FIRST && abl_on) {   // no LDS reads: the MFMAs run on whatever the (opaque) registers hold
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg) asm volatile("" : "=v"(ar[r][pg]));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) asm volatile("" : "=v"(bf[dy][cg]));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], acc[m][pg][cg], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) bf[0][cg] = bq[cg * 64];
 #pragma unroll
@@ -525,6 +560,12 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    auto seam_keep_halo = [&]() {   // the same with the NLOAD halo loads issued behind the B DMA still in flight
+        static_assert(NLOAD == 6, "vmcnt immediate below");
+        if (H16_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+    };
     auto chunk_seam = [&]() {   // between chunks: the halo tile is replaced as well
         __syncthreads();
         halo_to_lds();
@@ -540,16 +581,14 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         const int cobase = nb * NTILE;
         const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + cobase + 4 * c16 + zs);   // column c16 of group cg = channel 4 c16 + cg
 #ifdef H16_TRACE
-        if (tid == 0 && first_item) trace[1] = __builtin_readcyclecounter();
+        tr_lap(tr_bnd);     // prologue of the first item / boundary of the later ones
 #endif
         substep(T{}, F{}, 0, 0); seam();
-        substep(F{}, F{}, 1, 1); seam();
-        request_halo(rsrc_in, 1, zs);
+        substep(F{}, F{}, 1, 1, 1); seam_keep_halo();
         substep(F{}, F{}, 2, 2); chunk_seam();
         for (int ck = 1; ck + 1 < NCHUNK; ++ck) {
             substep(F{}, F{}, 3 * ck, 0); seam();
-            substep(F{}, F{}, 3 * ck + 1, 1); seam();
-            request_halo(rsrc_in, ck + 1, zs);
+            substep(F{}, F{}, 3 * ck + 1, 1, ck + 1); seam_keep_halo();
             substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam();
         }
         substep(F{}, F{}, NSUB - 3, 0); seam();
@@ -558,7 +597,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 
 #ifdef H16_TRACE
         asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
-        if (tid == 0 && first_item) trace[2] = __builtin_readcyclecounter();
+        tr_lap(tr_main);
 #endif
         {   // no barrier: the epilogue touches no LDS (round 4), so a wave stores while its siblings finish their MFMAs
             int lane_e;    // opaque copy of the lane id: keeps the epilogue's address arithmetic out of the item loop's registers
@@ -572,26 +611,26 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             }
         }
 #ifdef H16_TRACE
-        if (tid == 0 && first_item) {
-            trace[3] = __builtin_readcyclecounter();
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            trace[5] = hwid; trace[6] = xcc;
-            trace[4] = __builtin_readcyclecounter();
-        }
-        first_item = false;
+        tr_lap(tr_epi);
+        ++tr_items;
 #endif
         if (!has_next) break;                                  // workgroup-uniform
         // ---- item boundary: the prefetched item becomes the current one ----
         n = n2; y0 = y02; x0 = x02; local = local2; nb = nb2;
+        if (H16_ABLATE) abl_on = true;
         rsrc_in = image_rsrc(n);
         __syncthreads();   // every wave has read its last fragments of this item: the halo planes may be written again
         halo_to_lds();     // its loads are younger than the B DMA issued with them: their arrival vouches for B buffer 0 as well
         decode_next();
         __syncthreads();
     }
+#ifdef H16_TRACE
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace[0] = tr_t0; trace[1] = tr_main; trace[2] = tr_epi; trace[3] = tr_bnd; trace[5] = tr_items;
+        trace[4] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -283,17 +283,19 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     auto make_v = [&](float (&v)[6][2], int part) {       // part 0: b = 0, 1, 2; part 1: b = 3, 4, 5
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            // the odd part of a +-p pair is p (t3 - p^2 t1)... / p^2: one fma for the bracket, and its factor rides on the two fmas that
+            // form the pair (round 4: 12 instead of 14 operations per channel; every constant is still an exact dyadic rational)
             if (part == 0) {
                 v[0][e] = __builtin_fmaf(1.265625f, t[0][e], __builtin_fmaf(-2.8125f, t[2][e], t[4][e]));
                 const float ev = __builtin_fmaf(-2.25f, t[2][e], t[4][e]);
-                const float od = __builtin_fmaf(-1.6875f, t[1][e], 0.75f * t[3][e]);
-                v[1][e] = ev + od;
-                v[2][e] = ev - od;
+                const float od = __builtin_fmaf(-2.25f, t[1][e], t[3][e]);          // (t3 - 9/4 t1); x 3/4 below
+                v[1][e] = __builtin_fmaf(0.75f, od, ev);
+                v[2][e] = __builtin_fmaf(-0.75f, od, ev);
             } else {
                 const float ev = __builtin_fmaf(-0.5625f, t[2][e], t[4][e]);
-                const float od = __builtin_fmaf(-0.84375f, t[1][e], 1.5f * t[3][e]);
-                v[3][e] = ev + od;
-                v[4][e] = ev - od;
+                const float od = __builtin_fmaf(-0.5625f, t[1][e], t[3][e]);         // (t3 - 9/16 t1); x 3/2 below
+                v[3][e] = __builtin_fmaf(1.5f, od, ev);
+                v[4][e] = __builtin_fmaf(-1.5f, od, ev);
                 v[5][e] = __builtin_fmaf(1.265625f, t[1][e], __builtin_fmaf(-2.8125f, t[3][e], t[5][e]));
             }
         }
@@ -352,7 +354,9 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
                     if (grp == 10) make_v(vnxt, 1);
                 }
                 if (DMA && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(rsrc_in, tpar, TB, ck + 2, grp - 6);
-                if (!MORE && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1)) dma_round(rsrc_next, tpar ^ 1, 2, 0, grp - 6);   // next tile, chunk 0 -> X
+                // next tile, chunk 0 -> X.  Only if there is one (workgroup-uniform: a scalar branch): one item per workgroup and a walker's
+                // last item used to issue the RW rounds against an all-sentinel offset table
+                if (!MORE && k == 1 && grp >= 6 && grp - 6 < RW && !(ABLATE & 1) && has_next) dma_round(rsrc_next, tpar ^ 1, 2, 0, grp - 6);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
 #ifdef CID_W42_ASM_MFMA
