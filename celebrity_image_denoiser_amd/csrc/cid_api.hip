@@ -439,6 +439,9 @@ int env_wg_per_cu(const char* name, int dflt, int hi) {
 }
 int g_wino42_wg_per_cu = env_wg_per_cu("CID_WINO42_WG_PER_CU", 2, 2);
 int g_half_wg_per_cu = env_wg_per_cu("CID_HALF_WG_PER_CU", 3, 3);   // k_conv3x3_h16, same meaning
+// CID_WINO42_XNB (environment, measurement aid): bit mask over the column-block counts NB (2, 4) whose walking launches give every XCD group ONE
+// column block (a.walk < 0, wino42_kernels.h) instead of walking all NB blocks of a tile back to back.  Default 0: profiles/r04_xnb_experiment.txt.
+int g_wino42_xnb = env_wg_per_cu("CID_WINO42_XNB", 0, 6);
 // CU count of the CURRENT device (the one the launch goes to), cached per device id: a process may drive unlike devices.
 int device_cus() {
     constexpr int MAXDEV = 64;
@@ -462,6 +465,10 @@ int wino42_grid(WinoArgs& a, int nb) {
     // spreads the same items over every CU (mid-size batches, N = 17..48 on the bottleneck layers).
     if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers || a.tiles_per_xcd < walkers) return items;
     a.walk = walkers;
+    if ((nb == 2 || nb == 4) && (g_wino42_xnb & nb)) {        // one column block per XCD group: 8 / nb tile ranges
+        a.tiles_per_xcd = cdiv(a.tiles_total, 8 / nb);
+        a.walk = -walkers;
+    }
     return 8 * walkers;
 }
 

@@ -119,10 +119,16 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     //                computes ALL NB column blocks of a tile back to back: the tile's input is fetched from HBM once and the other
     //                NB - 1 reads hit this XCD's L2 (with one column block per workgroup the NB readers of a tile drifted apart
     //                and the input was fetched 2-4 times: 2.7 GB per launch for <256,256> against 0.27 GB of input).
+    //   a.walk  < 0 (NB = 2 or 4 only): -walk walkers per XCD group, and an XCD group keeps ONE column block: group x computes block x % NB of
+    //                the tiles of tile range x / NB (8 / NB ranges of tiles_per_xcd tiles).  Its NB-th of U (1.6 MB of bottleneck.2's 6.3 MB)
+    //                then stays in the XCD's 4 MiB L2; the price is that every tile's input is read by NB XCDs (round 4).
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    int local = a.walk ? slot0 : slot0 / NB;                // tile index inside the XCD group
-    int nb = a.walk ? 0 : slot0 - local * NB;
-    int mt = xcd * a.tiles_per_xcd + local;
+    const int walkers = a.walk < 0 ? -a.walk : a.walk;
+    const bool xnb = NB > 1 && a.walk < 0;
+    const int tgrp = xnb ? xcd / NB : xcd;                  // tile range of this XCD group
+    int local = walkers ? slot0 : slot0 / NB;               // tile index inside the range
+    int nb = walkers ? (xnb ? xcd % NB : 0) : slot0 - local * NB;
+    int mt = tgrp * a.tiles_per_xcd + local;
     if (!(mt < a.tiles_total && local < a.tiles_per_xcd)) return;
     int n, ty, tx;
     decode_tile(mt, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
@@ -178,11 +184,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_wino42_conv(const WinoArgs a) {
     int n2, y02, x02;
     int nb2, local2;
     auto decode_next = [&]() {   // the item after (local, nb)
-        n2 = n; y02 = y0; x02 = x0; local2 = local; nb2 = nb + 1;
-        has_next = a.walk != 0;
+        n2 = n; y02 = y0; x02 = x0; local2 = local; nb2 = xnb ? NB : nb + 1;
+        has_next = walkers != 0;
         if (has_next && nb2 == NB) {                          // next tile of the walk
-            nb2 = 0; local2 = local + a.walk;
-            const int mt2 = xcd * a.tiles_per_xcd + local2;
+            nb2 = xnb ? nb : 0; local2 = local + walkers;
+            const int mt2 = tgrp * a.tiles_per_xcd + local2;
             has_next = mt2 < a.tiles_total && local2 < a.tiles_per_xcd;
             if (has_next) {
                 int ty2, tx2;
