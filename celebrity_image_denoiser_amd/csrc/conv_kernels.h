@@ -109,7 +109,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // 32*ns + (lane&31) for the k-th staged pixel of this lane (k in [0, NPIX/2)), `pix(k)` its pixel index
 // in [0, NPIX); `ptr(px)` returns the global address of channel 0 of the slab for pixel px, or nullptr
 // to skip it.
-template <int NPIX, int WSF = WS_STRIDE, typename ValFn, typename PixFn, typename PtrFn>
+template <int NPIX, int WSF = WS_STRIDE, bool NT = false, typename ValFn, typename PixFn, typename PtrFn>
 __device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixFn pix, PtrFn ptr) {
     const int i = lane & 31;
 #pragma unroll
@@ -124,14 +124,17 @@ __device__ __forceinline__ void wide_store(float* stg, int lane, ValFn val, PixF
         const int px = it * 4 + (lane >> 4);
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + px * WSF + (lane & 15) * 4);
         float* g = ptr(px);
-        if (g) *reinterpret_cast<f32x4*>(g + (lane & 15) * 4) = v;
+        if (g) {
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g + (lane & 15) * 4));
+            else *reinterpret_cast<f32x4*>(g + (lane & 15) * 4) = v;
+        }
     }
     wave_lds_fence();
 }
 
 // Interior-tile variants: the slab's pixels are `stride` floats (halfs) apart starting at the wave-uniform `base`, all in
 // range.  One per-lane offset for the whole tail, the rest is scalar: no per-pixel pointer or bounds arithmetic.
-template <int NPIX, int WSF = WS_STRIDE, typename ValFn, typename PixFn>
+template <int NPIX, int WSF = WS_STRIDE, bool NT = false, typename ValFn, typename PixFn>
 __device__ __forceinline__ void wide_store_full(float* stg, int lane, ValFn val, PixFn pix, float* base, int stride) {
     const int i = lane & 31;
 #pragma unroll
@@ -145,7 +148,8 @@ __device__ __forceinline__ void wide_store_full(float* stg, int lane, ValFn val,
 #pragma unroll
     for (int it = 0; it < NPIX / 4; ++it) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * WSF + (lane & 15) * 4);
-        *reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off) = v;
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off));
+        else *reinterpret_cast<f32x4*>(base + (size_t)(it * 4) * stride + lane_off) = v;
     }
     wave_lds_fence();
 }
@@ -577,9 +581,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_conv_head(const HeadArgs a) {
                 const int xq = x0 + 16 * q;
                 float* orow = static_cast<float*>(a.out) + ((size_t)(n * a.H + y) * a.W) * 64;
                 if (full)
-                    wide_store_full<16, WS_UNPADDED>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
+                    wide_store_full<16, WS_UNPADDED, true>(stg, lane, val, pix, orow + (size_t)xq * 64, 64);
                 else
-                    wide_store<16, WS_UNPADDED>(stg, lane, val, pix,
+                    wide_store<16, WS_UNPADDED, true>(stg, lane, val, pix,
                                                 [&](int px) -> float* { return (rowok && xq + px < a.W) ? orow + (size_t)(xq + px) * 64 : nullptr; });
             }
         }
