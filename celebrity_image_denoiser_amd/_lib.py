@@ -54,6 +54,7 @@ SYMBOLS = {
     "cid_debug_poison_lds": (_c.c_int, [_c.c_void_p]),
     "cid_debug_winograd_workgroups_per_cu": (_c.c_int, [_c.c_int]),
     "cid_debug_half_workgroups_per_cu": (_c.c_int, [_c.c_int]),
+    "cid_debug_winograd_column_block_per_xcd": (_c.c_int, [_c.c_int]),
     "cid_set_compute_dtype": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_compute_dtype": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_launch_work_ex": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),

@@ -463,7 +463,11 @@ int wino42_grid(WinoArgs& a, int nb) {
     // Walkers are indexed by TILE (a walker runs all nb column blocks of its tiles back to back), so walking needs at least one
     // tile per walker: with fewer, only tiles_per_xcd of the slots would work, each nb items deep, where one item per workgroup
     // spreads the same items over every CU (mid-size batches, N = 17..48 on the bottleneck layers).
+#ifdef CID_OLD_WALK_RULE   // A/B build only (profiles/r04_ab_midbatch_walk_rule.txt): round 3's rule, walking as soon as there are more items than walkers
+    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers) return items;
+#else
     if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers || a.tiles_per_xcd < walkers) return items;
+#endif
     a.walk = walkers;
     if ((nb == 2 || nb == 4) && (g_wino42_xnb & nb)) {        // one column block per XCD group: 8 / nb tile ranges
         a.tiles_per_xcd = cdiv(a.tiles_total, 8 / nb);
@@ -588,7 +592,11 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         // sibling workgroups dispatched back to back share one fetch (profiles/r03_ab_f16_walk.txt).
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
+#ifdef CID_OLD_WALK_RULE
+        if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers) { a.walk = walkers; grid = 8 * walkers; }
+#else
         if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
+#endif
         hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();
@@ -907,6 +915,11 @@ int cid_view_u8(const float* in_nchw, void* out_u8_nhwc, int N, int H, int W, vo
 int cid_debug_winograd_workgroups_per_cu(int k) {
     const int prev = g_wino42_wg_per_cu;
     if (k >= 0) g_wino42_wg_per_cu = k > 2 ? 2 : k;   // two is what the kernel's LDS use (75 KiB) admits
+    return prev;
+}
+int cid_debug_winograd_column_block_per_xcd(int mask) {
+    const int prev = g_wino42_xnb;
+    if (mask >= 0) g_wino42_xnb = mask & 6;
     return prev;
 }
 int cid_debug_half_workgroups_per_cu(int k) {

@@ -262,6 +262,10 @@ int cid_debug_poison_lds(void* stream);
  * Returns the previous value; a negative argument only queries.
  */
 int cid_debug_winograd_workgroups_per_cu(int k);
+/* Measurement aid (process-wide; default 0): bit mask over the column-block counts NB (2, 4) whose WALKING Winograd F(4x2) launches give every XCD
+ * group ONE column block of a tile range instead of all NB blocks of its tiles back to back (profiles/r04_xnb_experiment.txt: bit-identical results,
+ * -3 % fabric traffic, +-0 time).  Returns the previous mask; a negative argument only queries. */
+int cid_debug_winograd_column_block_per_xcd(int mask);
 /* The same for the 3x3 launches of the fp16-storage path (k_conv3x3_h16): default 3 workgroups per CU, 0 = one item per workgroup. */
 int cid_debug_half_workgroups_per_cu(int k);
 

@@ -527,6 +527,17 @@ def test_walking_full_size_every_stage_bit_equal_and_stable(weight_sets, dtype):
             for s in stages:
                 assert torch.equal(s0[s], s1[s]), (rep, s, int((s0[s] != s1[s]).sum()))
             assert torch.equal(y0, y1), rep
+        if dtype == "f32":
+            # round 4's measured option: one column block per XCD group on the launches with 2 / 4 column blocks (a.walk < 0) — another
+            # walk order over the same items, so the same bits at every stage
+            assert L.cid_debug_winograd_column_block_per_xcd(6) == 0
+            try:
+                y2, s2 = run(prev)
+            finally:
+                assert L.cid_debug_winograd_column_block_per_xcd(0) == 6
+            for s in stages:
+                assert torch.equal(s0[s], s2[s]), ("xnb", s, int((s0[s] != s2[s]).sum()))
+            assert torch.equal(y0, y2)
     finally:
         knob(prev)
 
