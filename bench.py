@@ -171,16 +171,10 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
     peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
     layers, exec_total = [], 0.0
     for li, ((name, kern, flops, nbytes, executed), ms_sum) in enumerate(zip(table, launch_ms)):
-        empty = flops == 0 and nbytes == 0
-        if f16 and not empty:   # half activations and weights; the caller-side fp32 tensors of the first/last launch stay fp32
+        if f16:   # half activations and weights; the caller-side fp32 tensors of the first/last launch stay fp32
             io = 4.0 * n_img * 3 * S * S
             nbytes = (nbytes - io) / 2 + io if li in (0, len(table) - 1) else nbytes / 2
         ms = ms_sum / max(nfw, 1)
-        if empty:   # an empty launch slot (fp16 path: down1[0] is computed inside down1[2]'s kernel; its work is counted there)
-            layers.append({"layer": name, "kernel": kern, "ms": round(ms, 4), "tflops_executed": 0.0, "tflops_algorithmic": 0.0, "gbs": 0.0,
-                           "bound": "none", "frac": None})
-            continue
-        ms = max(ms, 1e-6)
         exec_total += executed
         t_mfma, t_hbm = executed / (peak_tf * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
@@ -189,7 +183,7 @@ def layer_report(table, launch_ms, nfw, n_img, S, f16):
                        "tflops_algorithmic": round(flops / (ms * 1e-3) / 1e12, 2),
                        "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "bound": bound,
                        "frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4)})
-    dom = max((i for i in range(len(layers)) if layers[i]["frac"] is not None), key=lambda i: layers[i]["ms"])
+    dom = max(range(len(layers)), key=lambda i: layers[i]["ms"])
     d = layers[dom]
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from separate rocprofv3 --pmc passes (profiles/README.md)
@@ -262,7 +256,7 @@ def extra_config(model, sd_default, tag, B, S, dtype, steps=5, warmup=2):
                "max_abs_err_vs_cpu_oracle": float(np.abs(got - ref).max()),
                "psnr_delta_db": abs(cid.psnr(got, clean_host[:1]) - cid.psnr(ref, clean_host[:1])),
                "slowest_launch": {k: roof[k] for k in ("layer", "kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
-               "min_layer_frac": min(l["frac"] for l in layers if l["frac"] is not None), "layer_fracs": {l["layer"]: l["frac"] for l in layers}}
+               "min_layer_frac": min(l["frac"] for l in layers), "layer_fracs": {l["layer"]: l["frac"] for l in layers}}
         del x, y
         return out
     finally:

@@ -15,7 +15,6 @@ CID_ALGO_DIRECT, CID_ALGO_WINOGRAD64, CID_ALGO_WINOGRAD42 = 0, 2, 3
 CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
 CID_DTYPE_F32, CID_DTYPE_F16 = 0, 1
 CID_TAIL_FUSED, CID_TAIL_BANDS, CID_TAIL_TILES = 0, 1, 2
-CID_HEAD_FUSED, CID_HEAD_SEPARATE = 0, 1
 
 # every symbol include/cid.h declares: (restype, argtypes)
 _c = ctypes
@@ -52,8 +51,6 @@ SYMBOLS = {
     "cid_get_conv_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_set_tail_algo": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "cid_get_tail_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
-    "cid_set_head_algo": (_c.c_int, [_c.c_void_p, _c.c_int]),
-    "cid_get_head_algo": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "cid_debug_poison_lds": (_c.c_int, [_c.c_void_p]),
     "cid_debug_winograd_workgroups_per_cu": (_c.c_int, [_c.c_int]),
     "cid_debug_half_workgroups_per_cu": (_c.c_int, [_c.c_int]),

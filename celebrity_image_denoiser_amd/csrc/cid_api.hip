@@ -72,7 +72,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, hf_off, total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -102,7 +102,6 @@ struct BlobLayout {
         tab42_off[0] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);   // its LDS slot tables, TC = 8 and 4
         tab42_off[1] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
         hz_off = o; o = align_up(o + 3 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused last layer: upconv1[2] as A fragments [3 row tiles][2 k-steps][64 lanes][8] halfs
-        hf_off = o; o = align_up(o + 2 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused head: down1[0] as A fragments [2 chunks][2 row tiles][64 lanes][8] halfs
         total = o;
     }
 };
@@ -281,8 +280,6 @@ struct cid_handle_s {
     std::string err;
     int dtype = CID_DTYPE_F32;         // storage type of activations/weights between the first and last kernel
     int tail_algo = CID_TAIL_FUSED;    // last layer: see cid_set_tail_algo
-    int head_algo = [] { const char* e = std::getenv("CID_HEAD_ALGO"); return e && std::atoi(e) == CID_HEAD_SEPARATE ? CID_HEAD_SEPARATE : CID_HEAD_FUSED; }();
-                                       // first layer on the fp16-storage path: see cid_set_head_algo (CID_HEAD_ALGO=1: same-box A/B runs start "separate")
     int algo = CID_ALGO_WINOGRAD42;    // 3x3 GEMM layers: Winograd F(4x2,3x3) (default), Winograd F(2x2,3x3) or CID_ALGO_DIRECT (9-tap implicit GEMM)
     std::vector<hipEvent_t> tev;       // armed timing events, (NL+1) per forward
     int tev_forwards = 0, tev_used = 0;
@@ -299,8 +296,6 @@ namespace {
 
 // The fused form lives in the epilogue of upconv1[0]'s kernel: the Winograd kernels on the fp32 path (not the 9-tap direct one), k_conv3x3_h16 on the
 // fp16-storage path (one 3x3 algorithm there, so always).
-// down1[0] computed inside down1[2]'s kernel (k_conv3x3_h16<64, 64, 1, false, HEAD>): fp16-storage path only.
-bool fused_head_active(cid_handle_t h) { return h->head_algo == CID_HEAD_FUSED && h->dtype == CID_DTYPE_F16; }
 bool fused_tail_active(cid_handle_t h) {
     return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || h->algo != CID_ALGO_DIRECT);
 }
@@ -607,27 +602,6 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
     return hipGetLastError();
 }
 
-// down1[2] (+ pool1) of the fp16-storage path with down1[0] computed on the fly from the network input (k_conv3x3_h16<64, 64, 1, false, HEAD>).
-hipError_t launch_down1_fused_h(hipStream_t s, const float* blob, const void* in, bool in_u8, const Window& src, int H, int W,
-                                void* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, void* pool, int N) {
-    GemmConvArgsHF a;
-    a.in = nullptr; a.w = reinterpret_cast<const _Float16*>(blob + kBlob.h_off[1]); a.bias = blob + kBlob.b_off[1];
-    a.out = static_cast<_Float16*>(out); a.pool = static_cast<_Float16*>(pool);
-    a.N = N; a.Hin = H; a.Win = W; a.in_ps = 64;
-    a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
-    const TileGrid g = tiles_for(N, Hc, Wc);
-    a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
-    a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty);
-    a.hin = in; a.src = src; a.in_u8 = in_u8 ? 1 : 0;
-    a.hw = reinterpret_cast<const _Float16*>(blob + kBlob.hf_off); a.hb = blob + kBlob.b_off[0];
-    a.walk = 0;
-    int grid = 8 * g.per_xcd;
-    const int walkers = g_half_wg_per_cu * device_cus() / 8;
-    if (g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // as launch_gemm_h
-    hipLaunchKernelGGL((k_conv3x3_h16<64, 64, 1, false, true>), dim3(grid), dim3(THREADS), 0, s, a);
-    return hipGetLastError();
-}
-
 // (H, W) = the network input.  `src` places the caller's image inside it (the band around it is uint8 0 = -1.0 normalised), `crop`
 // is the window of the network output the caller's tensor receives; null = identity (no padding, whole output).
 int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_fmt, int N, int H, int W, void* ws, size_t ws_bytes,
@@ -663,14 +637,6 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
         ++li;                                                                              \
     } while (0)
 
-    const bool fused_head = fused_head_active(h);
-    if (fused_head) {
-        // fp16-storage path (round 4): down1[0] is computed inside down1[2]'s kernel from the network input; launch 0 is empty (its event pair
-        // brackets nothing) and t0 is never written.                                       app.py:43-48
-        STEP(hipSuccess);
-        const Window src = src_win ? *src_win : Window{0, 0, H, W};
-        STEP(launch_down1_fused_h(s, blob, in, in_fmt == CID_FMT_U8_NHWC, src, H, W, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N));
-    } else {
     {   // down1[0]: Conv 3->64 + ReLU, NCHW in -> NHWC t0            app.py:43-44
         HeadArgs a;
         a.in = in; a.w = blob + (h->dtype == CID_DTYPE_F16 ? kBlob.h_off[0] : kBlob.w_off[0]); a.bias = blob + kBlob.b_off[0]; a.out = B[T0];
@@ -684,7 +650,6 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
     }
     // down1[2] + ReLU -> e1 into cat1[:, 64:128] (cropped to Hu1 x Wu1), pool1 -> p1     app.py:45-48,97-100
     STEP((launch_layer<64, 64, 1>(h, s, blob, 1, B[T0], H, W, 64, B[CAT1], 128, 64, 2 * d.H1, 2 * d.W1, d.Hu1, d.Wu1, B[P1], N)));
-    }
     // down2[0] + ReLU                                                                    app.py:51-52
     STEP((launch_layer<64, 128, 0>(h, s, blob, 2, B[P1], d.H1, d.W1, 64, B[T1], 128, 0, d.H1, d.W1, d.H1, d.W1, nullptr, N)));
     // down2[2] + ReLU -> e2 into cat2[:, 128:256] (cropped), pool2 -> p2                 app.py:53-56,90-93
@@ -818,8 +783,6 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                     const int tap = k / 3, c = k % 3;
                     const float v = k < 27 ? data[ref_index(L, co, c, tap / 3, tap % 3)] : 0.f;
                     hd[((co & 3) * 64 + (k >> 3) * 16 + ((co >> 2) & 15)) * 8 + (k & 7)] = (_Float16)v;
-                    // and as the A operand of the fused form (k_conv3x3_h16<.., HEAD>): row = channel, [chunk co / 32][row tile (co / 16) % 2][lane = 16 (k / 8) + co % 16][k % 8]
-                    reinterpret_cast<_Float16*>(h->staging.data() + kBlob.hf_off)[(((co >> 5) * 2 + ((co >> 4) & 1)) * 64 + (k >> 3) * 16 + (co & 15)) * 8 + (k & 7)] = (_Float16)v;
                 }
         }
     }
@@ -1026,7 +989,6 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) {
         if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true>" : "k_conv_tail_zh<";
-        if (i <= 1 && fused_head_active(h)) return i == 0 ? "(none: fused into down1.2)" : "k_conv3x3_h16<64, 64, 1, false, true>";
         return kHalfKernelNames[i];
     }
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];
@@ -1044,17 +1006,6 @@ int cid_set_tail_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
     if (algo != CID_TAIL_FUSED && algo != CID_TAIL_BANDS && algo != CID_TAIL_TILES) return fail(h, CID_ERR_INVALID, "cid_set_tail_algo: unknown algorithm");
     h->tail_algo = algo;
-    return CID_OK;
-}
-int cid_set_head_algo(cid_handle_t h, int algo) {
-    if (!h) return CID_ERR_INVALID;
-    if (algo != CID_HEAD_FUSED && algo != CID_HEAD_SEPARATE) return fail(h, CID_ERR_INVALID, "cid_set_head_algo: unknown algorithm");
-    h->head_algo = algo;
-    return CID_OK;
-}
-int cid_get_head_algo(cid_handle_t h, int* algo) {
-    if (!h || !algo) return CID_ERR_INVALID;
-    *algo = h->head_algo;
     return CID_OK;
 }
 int cid_get_tail_algo(cid_handle_t h, int* algo) {
@@ -1229,19 +1180,6 @@ int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes) {
 // writes 27 z planes instead of 64 channels; launch 11 is the shifted sum (no multiply-adds) over those planes.
 int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops, double* bytes) {
     const int rc = cid_launch_work(i, N, H, W, flops, bytes);
-    if (rc == CID_OK && h && fused_head_active(h) && i <= 1) {
-        // launch 0 is empty; launch 1 carries both layers' FLOPs, reads the 3-channel network input instead of the 64-channel t0
-        // (fp32 tensor of the caller: counted at twice its size here, because bench.py halves this path's per-launch bytes)
-        double f0, b0;
-        cid_launch_work(0, N, H, W, &f0, &b0);
-        if (i == 0) { *flops = 0.0; *bytes = 0.0; }
-        else {
-            const double px = (double)N * H * W;
-            *flops += f0;
-            *bytes += 4.0 * px * (2.0 * 3 - 64) + 4.0 * (ref_weight_count(kLayers[0]) + 64);
-        }
-        return rc;
-    }
     if (rc != CID_OK || !h || !fused_tail_active(h) || i < 10) return rc;
     Dims d;
     make_dims(N, H, W, d);

@@ -40,15 +40,6 @@ struct GemmConvArgsH {
     // `pool` = upconv1[2]'s weights as A fragments, [3 row tiles][2 k-steps][64 lanes][8] halfs (cid_api.hip, hz_off)
 };
 
-// k_conv3x3_h16<64, 64, 1, false, HEAD>: down1[2] with down1[0] (the head) computed on the fly (round 4) — the extra arguments
-struct GemmConvArgsHF : GemmConvArgsH {
-    const void* hin;        // the NETWORK input: fp32 NCHW [N,3,src.H,src.W], or (in_u8) uint8 NHWC [N,src.H,src.W,3]   (k_conv_head_h16's `in`)
-    Window src;             // where the caller's image sits inside the network input [Hin, Win]
-    const _Float16* hw;     // down1[0]'s weights as A fragments: [2 chunks][2 row tiles][64 lanes][8] halfs (cid_api.hip, hf_off)
-    const float* hb;        // down1[0]'s bias [64]
-    int in_u8;
-};
-
 // ---------------------------------------------------------------------------------------------
 // k_convt_t16 — the transposed convolutions of the fp16-storage path: up2 / up1 = ConvTranspose2d(C, C/2, 2, stride=2) (app.py:65,73)
 // as a STREAMING kernel (round 3).  At fp16 a 2x2 stride-2 ConvT is bound by HBM (171 FLOP/B at CIN = 256, 85 at CIN = 128, against a
@@ -371,15 +362,8 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     so an item's prologue (B DMA + halo request + their HBM latency, ~5-7k cycles beside 20-40k of work) is paid once per
 //     workgroup.  Everything renewed per item (B offset, halo offsets, image descriptor) is derived from per-item opaque values, or
 //     hipcc hoists it out of the item loop into registers this 168-register kernel does not have.
-//   * (r4) HEAD (down1[2] only): the layer's input t0 = relu(down1[0](x)) is never stored.  K = 27 of the head fits ONE K = 32 step of
-//     v_mfma_f32_16x16x32_f16, so a 16-pixel x 16-channel tile of t0 is a single MFMA: per 32-channel chunk the workgroup computes its
-//     10x34 halo tile itself (44 MFMAs beside the chunk's 576) from a planar half copy of the 12x36x3 input patch in LDS (2.6 KB), with
-//     the WEIGHTS as rows — a lane of the result holds four consecutive channels of ONE pixel = one ds_write_b64 into the halo planes —
-//     bias, ReLU, rounding to half as k_conv_head_h16 does, zeros outside the image (this layer's padding).  The 0.24 ms launch, t0's
-//     1.07 GB of writes and its 1.55 GB of halo reads go; the kernel loses the 24 halo staging registers.
-template <int CIN, int COUT, int MODE, bool ZOUT = false, bool HEAD = false>
-__global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::conditional_t<HEAD, GemmConvArgsHF, GemmConvArgsH> a) {
-    static_assert(!HEAD || (CIN == 64 && !ZOUT), "the fused head produces down1[0]'s 64 channels");
+template <int CIN, int COUT, int MODE, bool ZOUT = false>
+__global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
 #ifndef CID_EXPERIMENTS
     static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
@@ -394,9 +378,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     constexpr int HALO_SLOTS = 4 * PLANE;
     // LDS: [B buffer 0][B buffer 1][halo planes]: 46.0 KiB -> three workgroups per CU (the epilogue stores from registers, round 4)
-    constexpr int PLW = 36, PLH = TILE_H + 4, PPLANE = PLW * PLH;         // HEAD: the input patch, [3][12][36] halfs behind the halo planes
-    constexpr int PATCH_SLOTS = HEAD ? (3 * PPLANE * 2 + 15) / 16 : 0;
-    constexpr int LDS_SLOTS = 2 * BSUB + HALO_SLOTS + PATCH_SLOTS;
+    constexpr int LDS_SLOTS = 2 * BSUB + HALO_SLOTS;
     constexpr int HB = 2 * BSUB;                                          // first halo slot
     static_assert(NSUB % 2 == 0, "the last sub-step must read B buffer 1");
     __shared__ f32x4 lds[LDS_SLOTS];
@@ -427,12 +409,10 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
     };
     // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot HB + (tid & 3) * PLANE + (tid >> 2) + 64 it
     bool abl_on = false;   // H16_ABLATE: a workgroup's first item runs in full (so LDS holds real data), the ablation applies from its second
-    constexpr int NPRE = HEAD ? 1 : NLOAD;   // HEAD: no halo loads at all (the tile is computed, see head_chunk below)
-    unsigned goff[NPRE];
+    unsigned goff[NLOAD];
     auto halo_offsets = [&](int ty0, int tx0, int lane_id) {
-        if constexpr (HEAD) return;
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it) {
+        for (int it = 0; it < NLOAD; ++it) {
             const int sidx = it * THREADS + lane_id;
             const int p = sidx >> 2, q = sidx & 3;
             const int hy = p / LW, hx = p - hy * LW;
@@ -443,118 +423,17 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
     };
     const int hbase = HB + (tid & 3) * PLANE + (tid >> 2);
     const bool halo_last = (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
-    f32x4 pre[NPRE];
+    f32x4 pre[NLOAD];
     auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
-        if constexpr (HEAD) return;
         if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * 64, 0));
+        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * 64, 0));
     };
     auto halo_to_lds = [&]() {
-        if constexpr (HEAD) return;
         if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
-        for (int it = 0; it < NPRE; ++it)
-            if (it + 1 < NPRE || halo_last) lds[hbase + it * 64] = pre[it];
-    };
-    // ---- HEAD: the network-input patch of an item (12 x 36 pixels x 3 channels, origin (y0 - 2, x0 - 2)) and t0's halo tile from it ----
-    constexpr int NPS = 3 * PPLANE, NPIT = HEAD ? (NPS + THREADS - 1) / THREADS : 1;   // 1296 elements: 6 per thread
-    float staged[NPIT];
-    _Float16* const img_h = reinterpret_cast<_Float16*>(lds + (2 * BSUB + HALO_SLOTS));
-    auto request_patch = [&](int pn, int ty0, int tx0, int lane_id) {
-        if constexpr (HEAD) {
-            const size_t img = (size_t)a.src.H * a.src.W * 3;   // elements per image in either input format
-            const unsigned long long pb = a.in_u8 ? (unsigned long long)(static_cast<const unsigned char*>(a.hin) + (size_t)pn * img)
-                                                  : (unsigned long long)(static_cast<const float*>(a.hin) + (size_t)pn * img);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pb), hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
-            const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0,
-                                                                                    (int)(a.in_u8 ? img : img * 4), 0x00020000);
-#pragma unroll
-            for (int it = 0; it < NPIT; ++it) {
-                const int sidx = it * THREADS + lane_id;
-                const int c = sidx / PPLANE, rem = sidx - c * PPLANE, pr = rem / PLW, pc = rem - pr * PLW;
-                const int gy = ty0 - 2 + pr, gx = tx0 - 2 + pc;                       // network-input coordinates
-                const bool net = sidx < NPS && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-                const int sy = gy - a.src.top, sx = gx - a.src.left;                  // the caller's image (conv_kernels.h, Window)
-                const bool ok = net && (unsigned)sy < (unsigned)a.src.H && (unsigned)sx < (unsigned)a.src.W;
-                // the image; the black band the server pads with (-1.0 once normalised); the head's zero padding (0 in the NORMALISED tensor)
-                const float fill = net ? -1.f : 0.f;
-                if (a.in_u8) {
-                    const unsigned go = ok ? (unsigned)((sy * a.src.W + sx) * 3 + c) : 0x7ffffff0u;
-                    const float t = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc_p, go, 0, 0);
-                    staged[it] = ok ? (t / 255.0f - 0.5f) / 0.5f : fill;
-                } else {
-                    const unsigned go = ok ? (unsigned)(((c * a.src.H + sy) * a.src.W + sx) * 4) : 0x7ffffff0u;
-                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_p, go, 0, 0));
-                    staged[it] = ok ? t : fill;
-                }
-            }
-        }
-    };
-    auto patch_to_lds = [&]() {
-        if constexpr (HEAD) {
-#pragma unroll
-            for (int it = 0; it < NPIT; ++it)
-                if (it * THREADS + tid < NPS) img_h[it * THREADS + tid] = (_Float16)staged[it];
-        }
-    };
-    // chunk ck (32 channels) of t0's 10x34 halo tile: 22 pixel tiles of 16, two row tiles of 16 channels — 44 MFMAs per workgroup.
-    // z^T-style product, the weights as ROWS: lane (column = pixel, row group kg) of the result holds channels 32 ck + 16 t + 4 kg + r of ONE
-    // pixel -> 8 bytes into plane 2 t + (kg >> 1), half (kg & 1) of the pixel's slot.  The pixel operand (k = 3 tap + c, as in
-    // k_conv_head_h16) is gathered with eight 2-byte reads from the planar patch.
-    // the chunk's weights (two row tiles of A fragments) and bias: requested BEFORE the barrier in front of head_chunk, so that their L2
-    // latency is covered by the wait for the other waves
-    f16x8 wf[HEAD ? 2 : 1];
-    f32x4 hbias[HEAD ? 2 : 1];
-    auto head_load = [&](int ck) {
-        if constexpr (HEAD) {
-            int lane_o;    // opaque per call, see head_chunk
-            asm volatile("v_mov_b32 %0, %1" : "=v"(lane_o) : "v"(tid & 63));
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                wf[t] = reinterpret_cast<const f16x8*>(a.hw)[(ck * 2 + t) * 64 + lane_o];
-                hbias[t] = *reinterpret_cast<const f32x4*>(a.hb + 32 * ck + 16 * t + 4 * (lane_o >> 4));
-            }
-        }
-    };
-    auto head_chunk = [&](int ck, int ty0, int tx0) {
-        if constexpr (HEAD) {
-            // everything lane-dependent here derives from an opaque copy of the lane id made per call: otherwise hipcc hoists the
-            // gather offsets (loop-invariant) out of the item loop and keeps them alive across the main loop
-            int lane_o;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(lane_o) : "v"(tid & 63));
-            const int c16 = lane_o & 15, kg = lane_o >> 4;
-            int koff[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = min(8 * kg + e, 26), tap = k / 3, c = k - 3 * tap;   // k >= 27 meets zero weights: any finite element will do
-                koff[e] = c * PPLANE + (tap / 3) * PLW + (tap % 3);
-            }
-#pragma unroll   // six pixel tiles per wave (five for waves 2, 3): straight-line code, two tiles between scheduling fences (a real loop made
-            // hipcc spill the 64 accumulators around it; fully free scheduling hoisted all 48 gathers and spilled 48 registers)
-            for (int j = 0; j < ((LPIX + 15) / 16 + 3) / 4; ++j) {
-                const int pt = wave_s + 4 * j;                                   // wave-uniform; tiles past the last one are computed and dropped
-                const int p = 16 * pt + c16, pcl = min(p, LPIX - 1);
-                const int hy = pcl / LW, hx = pcl - hy * LW;
-                const int pbase = hy * PLW + hx;
-                f16x8 bf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bf[e] = img_h[pbase + koff[e]];
-                const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-                const bool in_img = (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;   // outside: this layer's zero padding
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 acc_h = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], bf, zero, 0, 0, 0);
-                    f16x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = in_img ? (_Float16)fmaxf(acc_h[r] + hbias[t][r], 0.f) : (_Float16)0.f;
-                    if (p < LPIX)
-                        *reinterpret_cast<f16x4*>(reinterpret_cast<unsigned char*>(&lds[HB + (2 * t + (kg >> 1)) * PLANE + p]) + (kg & 1) * 8) = v;
-                }
-                if (j == 2) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int it = 0; it < NLOAD; ++it)
+            if (it + 1 < NLOAD || halo_last) lds[hbase + it * 64] = pre[it];
     };
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
@@ -598,13 +477,6 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
     dma_b(nb * NSUB * (BSUB * 16), 0);
     request_halo(rsrc_in, 0, 0);
     halo_to_lds();
-    if constexpr (HEAD) {
-        request_patch(n, y0, x0, tid);
-        head_load(0);
-        patch_to_lds();
-        __syncthreads();                                  // the patch is complete
-        head_chunk(0, y0, x0);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // B sub-chunk 0 landed (this wave); past the barrier: every wave's part
     __syncthreads();
     decode_next();
@@ -632,12 +504,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
             if (req_ck >= 0) request_halo(rsrc_in, req_ck, zs);
         } else {                                                // B first: the halo loads behind it in the queue then vouch for it
             dma_b(nb2 * NSUB * (BSUB * 16) + zs, 0);
-            if constexpr (HEAD) {
-                request_patch(n2, y02, x02, tid + zs);    // six 1- or 4-byte loads per lane instead of six quads
-            } else {
-                halo_offsets(y02, x02, tid + zs);
-                request_halo(image_rsrc(n2), 0, zs);
-            }
+            halo_offsets(y02, x02, tid + zs);
+            request_halo(image_rsrc(n2), 0, zs);
         }
         f16x8 ar[4][2], bf[3][4];
         if ((H16_ABLATE & 8) && !FIRST && abl_on) {   // no LDS reads: the MFMAs run on whatever the (opaque) registers hold
@@ -694,15 +562,13 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
     };
     auto seam_keep_halo = [&]() {   // the same with the NLOAD halo loads issued behind the B DMA still in flight
         static_assert(NLOAD == 6, "vmcnt immediate below");
-        if (HEAD || (H16_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (H16_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
     };
-    auto chunk_seam = [&](int next_ck) {   // between chunks: the halo tile is replaced as well
-        head_load(next_ck);
+    auto chunk_seam = [&]() {   // between chunks: the halo tile is replaced as well
         __syncthreads();
         halo_to_lds();
-        head_chunk(next_ck, y0, x0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -719,11 +585,11 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
 #endif
         substep(T{}, F{}, 0, 0); seam();
         substep(F{}, F{}, 1, 1, 1); seam_keep_halo();
-        substep(F{}, F{}, 2, 2); chunk_seam(1);
+        substep(F{}, F{}, 2, 2); chunk_seam();
         for (int ck = 1; ck + 1 < NCHUNK; ++ck) {
             substep(F{}, F{}, 3 * ck, 0); seam();
             substep(F{}, F{}, 3 * ck + 1, 1, ck + 1); seam_keep_halo();
-            substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam(ck + 1);
+            substep(F{}, F{}, 3 * ck + 2, 2); chunk_seam();
         }
         substep(F{}, F{}, NSUB - 3, 0); seam();
         substep(F{}, F{}, NSUB - 2, 1); seam();
@@ -753,14 +619,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const std::condition
         n = n2; y0 = y02; x0 = x02; local = local2; nb = nb2;
         if (H16_ABLATE) abl_on = true;
         rsrc_in = image_rsrc(n);
-        head_load(0);
         __syncthreads();   // every wave has read its last fragments of this item: the halo planes may be written again
         halo_to_lds();     // its loads are younger than the B DMA issued with them: their arrival vouches for B buffer 0 as well
-        if constexpr (HEAD) {
-            patch_to_lds();                               // (the same holds for the patch loads)
-            __syncthreads();
-            head_chunk(0, y0, x0);
-        }
         decode_next();
         __syncthreads();
     }

@@ -399,21 +399,6 @@ class DenoiseGenerator(nn.Module):
         _lib.check(self._cid, _lib.lib().cid_set_tail_algo(self._cid, algo))
 
     @property
-    def head_algo(self) -> str:
-        """First layer on the fp16-storage path: "fused" (default: down1[0] is computed inside down1[2]'s kernel, its 64-channel output never
-        exists) or "separate" (its own launch).  Same bits either way; the fp32 path ignores it (no fused form there)."""
-        a = ctypes.c_int()
-        _lib.check(self._cid, _lib.lib().cid_get_head_algo(self._cid, ctypes.byref(a)))
-        return "separate" if a.value == _lib.CID_HEAD_SEPARATE else "fused"
-
-    @head_algo.setter
-    def head_algo(self, name: str) -> None:
-        algo = {"fused": _lib.CID_HEAD_FUSED, "separate": _lib.CID_HEAD_SEPARATE}.get(name)
-        if algo is None:
-            raise ValueError("head_algo must be 'fused' or 'separate'")
-        _lib.check(self._cid, _lib.lib().cid_set_head_algo(self._cid, algo))
-
-    @property
     def compute_dtype(self) -> str:
         """"f32" (default: the reference's arithmetic) or "f16" (half storage between the first and last kernel,
         fp16 MFMA with fp32 accumulators; BASELINE configs[4]).  Inputs/outputs keep their formats."""

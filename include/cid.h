@@ -210,16 +210,6 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
 enum { CID_TAIL_FUSED = 0, CID_TAIL_BANDS = 1, CID_TAIL_TILES = 2 };
 int cid_set_tail_algo(cid_handle_t h, int algo);
 int cid_get_tail_algo(cid_handle_t h, int* algo);
-/*
- * How the FIRST layer (down1[0] = Conv2d(3,64,3,p=1) + ReLU, backend/app.py:43-44,81) runs on the fp16-storage path (CID_DTYPE_F16); same function, same bits:
- *   CID_HEAD_FUSED     (default, round 4) computed on the fly inside down1[2]'s kernel: with K = 27 a 16-pixel x 16-channel tile of it is ONE fp16 MFMA,
- *                      so every workgroup forms the halo tile of its input itself from the 3-channel network input; the 64-channel tensor is
- *                      never written or read, launch 0 of the forward is empty
- *   CID_HEAD_SEPARATE  its own launch (k_conv_head_h16), as on the fp32 path (where the head has no fused form: CID_DTYPE_F32 ignores this setting)
- */
-enum { CID_HEAD_FUSED = 0, CID_HEAD_SEPARATE = 1 };
-int cid_set_head_algo(cid_handle_t h, int algo);
-int cid_get_head_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
