@@ -502,7 +502,9 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             // waits for all but the six youngest operations (= the B DMA only), and the halo loads have two sub-steps to land instead
             // of one (round 4; rounds 2-3 requested them in front of the last sub-step)
             if (req_ck >= 0) request_halo(rsrc_in, req_ck, zs);
-        } else {                                                // B first: the halo loads behind it in the queue then vouch for it
+        } else if (has_next) {                                  // B first: the halo loads behind it in the queue then vouch for it
+            // (workgroup-uniform, a scalar branch: one item per workgroup — the CIN = 256 layers — and a walker's last item have no next item;
+            // rounds 2-3 fetched 12 KiB of weights and a 21 KiB halo chunk for nobody there: ADVICE r3)
             dma_b(nb2 * NSUB * (BSUB * 16) + zs, 0);
             halo_offsets(y02, x02, tid + zs);
             request_halo(image_rsrc(n2), 0, zs);
