@@ -585,6 +585,7 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         const int wgs = device_cus() * 2 / CG::CB;
         hipLaunchKernelGGL((k_convt_t16<CIN, COUT>), dim3(a.tiles_total < wgs ? a.tiles_total : wgs), dim3(64 * CG::NW), 0, s, a);
     } else if constexpr (MODE != 2) {
+        if (in_ps != CIN) return hipErrorInvalidValue;   // k_conv3x3_h16 takes the pixel stride of its input as CIN (true of every layer of this network)
         // walking workgroups (conv_kernels_f16.h): three per CU (47 KiB of LDS, <= 168 VGPRs) once there are more items than that —
         // on the layers with CIN <= 128, where an item is short beside its prologue (same-box: down1.2 -15 %, down2.0 -11 %, the
         // CIN = 128 layers -0.3...-1.5 %).  With CIN = 256 walking LOSES 3-5 %: a tile's NB column blocks then run one after the

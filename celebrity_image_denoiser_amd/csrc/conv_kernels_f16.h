@@ -401,11 +401,13 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         decode_tile(xcd * a.tiles_per_xcd + local, a.tiles_x, a.tiles_y, a.rcp_x, a.rcp_xy, n, ty, tx);
         y0 = ty * TILE_H; x0 = tx * TILE_W;
     }
-    const size_t img_elems = (size_t)a.Hin * a.Win * a.in_ps;
+    // the input tensor's pixel stride is the layer's CIN on every layer of this network (cat1 / cat2 hold exactly the channels their
+    // consumer reads): a compile-time constant instead of a kernel argument held in an SGPR (the host asserts it)
+    const size_t img_elems = (size_t)a.Hin * a.Win * CIN;
     auto image_rsrc = [&](int img) {   // base through readfirstlane: the descriptor must live in SGPRs
         const unsigned long long p = (unsigned long long)(a.in + (size_t)img * img_elems);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * a.in_ps * 2, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * CIN * 2, 0x00020000);
     };
     // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot HB + (tid & 3) * PLANE + (tid >> 2) + 64 it
     bool abl_on = false;   // H16_ABLATE: a workgroup's first item runs in full (so LDS holds real data), the ablation applies from its second
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             const int hy = p / LW, hx = p - hy * LW;
             const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
             const bool ok = p < LPIX && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-            goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * a.in_ps + q * 8) * 2) : 0x7ffffff0u;
+            goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * CIN + q * 8) * 2) : 0x7ffffff0u;
         }
     };
     const int hbase = HB + (tid & 3) * PLANE + (tid >> 2);
