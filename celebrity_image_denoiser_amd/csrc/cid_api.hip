@@ -463,11 +463,7 @@ int wino42_grid(WinoArgs& a, int nb) {
     // Walkers are indexed by TILE (a walker runs all nb column blocks of its tiles back to back), so walking needs at least one
     // tile per walker: with fewer, only tiles_per_xcd of the slots would work, each nb items deep, where one item per workgroup
     // spreads the same items over every CU (mid-size batches, N = 17..48 on the bottleneck layers).
-#ifdef CID_OLD_WALK_RULE   // A/B build only (profiles/r04_ab_midbatch_walk_rule.txt): round 3's rule, walking as soon as there are more items than walkers
-    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers) return items;
-#else
-    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers || a.tiles_per_xcd < walkers) return items;
-#endif
+    if (per_cu <= 0 || walkers < 1 || items <= 8 * walkers || a.tiles_per_xcd < walkers) return items;   // same-box against round 3's rule: profiles/r04_ab_midbatch_walk_rule.txt
     a.walk = walkers;
     if ((nb == 2 || nb == 4) && (g_wino42_xnb & nb)) {        // one column block per XCD group: 8 / nb tile ranges
         a.tiles_per_xcd = cdiv(a.tiles_total, 8 / nb);
@@ -593,11 +589,7 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         // sibling workgroups dispatched back to back share one fetch (profiles/r03_ab_f16_walk.txt).
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
-#ifdef CID_OLD_WALK_RULE
-        if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers) { a.walk = walkers; grid = 8 * walkers; }
-#else
         if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
-#endif
         hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();

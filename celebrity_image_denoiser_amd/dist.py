@@ -131,7 +131,7 @@ class WeightsComm:
     @classmethod
     def for_group(cls, device: torch.device, group: Optional[dist.ProcessGroup] = None) -> Tuple[Optional["WeightsComm"], bool]:
         """-> (communicator or None, True if it was set up by this call)."""
-        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        pg = group if group is not None else dist.group.WORLD      # the default process group object (a new one after every init_process_group)
         key = (id(pg), str(device))
         hit = cls._cache.get(key)
         if hit is not None and hit[0] is pg and hit[1]._comm:
