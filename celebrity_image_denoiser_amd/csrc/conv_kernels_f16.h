@@ -649,7 +649,11 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 //   * stores: h16_store_row (bias, ReLU, 8-byte stores straight from the accumulators: whole 128-byte lines), one output row at a time.
 template <bool IN_U8>
 __global__ void __launch_bounds__(THREADS, 4) k_conv_head_h16(const HeadArgs a) {
-    constexpr int LW = 36, LH = TILE_H + 2, PLANE = LW * LH;
+    // rows of 40 halfs, planes of 406: with these strides the eight 2-byte gathers of an A fragment (lane = (pixel, k-group), k = 3 tap + c) put the
+    // two k-groups of each 32-lane half on disjoint banks for every tap, row and pixel group (exhaustive search over row / plane paddings, round 4;
+    // rows of 36 and planes of 360 had 0.56 extra LDS cycles per gather: 46 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE in r3, 33 % after the staging went)
+    constexpr int LW = 40, LH = TILE_H + 2, PLANE = 406;
+    static_assert(PLANE >= LW * LH, "plane holds the 10-row patch");
     constexpr int IMG_BYTES = (3 * PLANE * 2 + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[IMG_BYTES];   // the planar half image (2.1 KB)
     _Float16* const img_h = reinterpret_cast<_Float16*>(lds_raw);
