@@ -376,7 +376,12 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * 3;
     constexpr int NB = COUT / NTILE;
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
-    constexpr int HALO_SLOTS = 4 * PLANE;
+    // (r4) ... and the k-group planes lie at 0, PLANE, 2 PLANE + 2, 3 PLANE + 2: the pairs (0,1) and (2,3) that share a ds_read_b128 service group stay
+    // 4 (mod 16) slots apart (reads conflict-free as before), while the four plane origins are now 0, 4, 2, 6 (mod 8) — the eight lanes of a
+    // ds_write_b128 service group (two neighbouring pixels x four k-groups, i.e. two coalesced 64-byte load quads) hit eight different slots:
+    // the halo writes, 2-way conflicted by construction in rounds 2-3, are conflict-free too (checked exhaustively with the reads)
+    constexpr int PLANE_GAP = 2;
+    constexpr int HALO_SLOTS = 4 * PLANE + PLANE_GAP;
     // LDS: [B buffer 0][B buffer 1][halo planes]: 46.0 KiB -> three workgroups per CU (the epilogue stores from registers, round 4)
     constexpr int LDS_SLOTS = 2 * BSUB + HALO_SLOTS;
     constexpr int HB = 2 * BSUB;                                          // first halo slot
@@ -423,7 +428,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
             goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * CIN + q * 8) * 2) : 0x7ffffff0u;
         }
     };
-    const int hbase = HB + (tid & 3) * PLANE + (tid >> 2);
+    const int hbase = HB + (tid & 3) * PLANE + ((tid & 2) ? PLANE_GAP : 0) + (tid >> 2);
     const bool halo_last = (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
     f32x4 pre[NLOAD];
     auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     // different slots (mod 16), and the halo stores (4 k-groups x 2 pixels per 8-lane group) are 2-way instead of 4-way.
     // Horizontal neighbours (2j, 2j+1) stay in one lane's four rows, which the pooled epilogue needs.
     const int prow = h16_prow(c16);
-    const int abase = HB + kg * PLANE + (2 * wave) * LW + prow;           // pixel (row 2*wave, column prow) of plane kg
+    const int abase = HB + kg * PLANE + ((kg & 2) ? PLANE_GAP : 0) + (2 * wave) * LW + prow;   // pixel (row 2*wave, column prow) of plane kg
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
     int wbase = 0, zs = 0;                                                // this item's B offset (bytes) and an opaque zero, renewed per item
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
