@@ -346,11 +346,14 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     [k-group][340 pixel slots] of 16-byte quads.  A ds_read_b128 is served in groups of 16 lanes — {0-3,12-15} of one k-group with
 //     {4-11} of the next (MI355X_MICROARCH.md, LDS): with planes 340 = 4 (mod 16) slots apart and the MFMA rows permuted (h16_prow)
 //     those cover 16 different slots (mod 16): every fragment READ is conflict-free, every (tap, row, half) address an immediate.
-//     The halo WRITES (ds_write_b128, served 8 lanes at a time: two pixels x four k-groups) are 2-way conflicted by construction, which is
-//     most of the 18-29 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE these launches show.  Round 4 measured the conflict-free alternatives
-//     (profiles/r04_ab_f16_epilogue_layouts.txt): 8 lanes on 8 different slots (mod 8) means the four lanes of a load quad fetch from
-//     different pixels instead of one pixel's 64 contiguous bytes — 8 consecutive pixels of a k-group per 8 lanes: 3x3 launches +3...4 %;
-//     lane pairs of 32 bytes: +1...3 %; planes of 352 slots with the round-3 quads (writes 4-way): +1.5 %.  Coalesced loads win;
+//     The halo WRITES (ds_write_b128, served 8 lanes at a time: two neighbouring pixels x four k-groups = two coalesced 64-byte load quads)
+//     were 2-way conflicted by construction in rounds 2-3 (plane origins 0, 4, 0, 4 mod 8): most of the 18-29 % SQ_LDS_BANK_CONFLICT /
+//     SQ_LDS_IDX_ACTIVE these launches showed.  Round 4 first measured the alternatives that re-order the PIECES (8 consecutive pixels of a
+//     k-group per 8 lanes: conflict-free but the four lanes of a load quad then fetch from different pixels, 3x3 launches +3...4 %; lane
+//     pairs of 32 bytes: +1...3 %; planes of 352 slots: writes 4-way, +1.5 %; profiles/r04_ab_f16_epilogue_layouts.txt) — coalesced loads
+//     win — and then found the layout that keeps them: two pad slots between planes 1 and 2 (PLANE_GAP below) put the plane origins at
+//     0, 4, 2, 6 (mod 8) while the read pairs (0,1) and (2,3) stay 4 (mod 16) apart: reads and writes conflict-free, 0.0 % measured on every
+//     launch of the path, 3x3 launches -0.3...-0.8 % (profiles/r04_ab_f16_plane_gap.txt);
 //   * B: packed on the host per lane, [chunk][dx][dy][channel group][lane = 16 kg + col][8] (cid_api.hip packed_index_h16);
 //     one tap column (12 KiB) at a time by LDS-DMA into one of two buffers — no staging registers, and the LDS stays under a
 //     third of the CU's; the halo tile of the next chunk waits in 24 registers over the chunk's last sub-step;
