@@ -9,7 +9,6 @@ distributed code; this is the build's own data-parallel driver.
 """
 from __future__ import annotations
 
-import atexit
 import time
 from typing import Dict, Optional, Tuple
 
@@ -143,7 +142,7 @@ class WeightsComm:
 
     @classmethod
     def close_all(cls) -> None:
-        """Destroy every cached communicator (also runs at interpreter exit).  Local; no collective."""
+        """Destroy every cached communicator.  Local; no collective."""
         for _, comm in list(cls._cache.values()):
             try:
                 comm.close()
@@ -163,7 +162,9 @@ class WeightsComm:
             pass
 
 
-atexit.register(WeightsComm.close_all)
+# Deliberately NOT registered with atexit: at interpreter exit the HIP runtime and torch's own process group may already be gone, and a
+# communicator that dies with its process needs no teardown.  Jobs that outlive their process group call WeightsComm.close_all() before
+# destroy_process_group() (bench.py does).
 
 
 def broadcast_weights(model: DenoiseGenerator, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> str:
