@@ -157,7 +157,10 @@ class WeightsComm:
 
     def __del__(self):
         try:
-            self.close()
+            import sys
+
+            if not sys.is_finalizing():      # at interpreter exit the runtimes underneath may already be gone: leave the communicator to the OS
+                self.close()
         except Exception:
             pass
 
