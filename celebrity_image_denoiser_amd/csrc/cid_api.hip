@@ -698,7 +698,7 @@ int run_forward(cid_handle_t h, const void* in, int in_fmt, void* out, int out_f
 
 extern "C" {
 
-const char* cid_version(void) { return "cid 0.3.0 (gfx950, fp32 MFMA: Winograd F(4x2,3x3) / F(2x2,3x3) + implicit GEMM)"; }
+const char* cid_version(void) { return "cid 0.4.0 (gfx950, fp32 MFMA: Winograd F(4x2,3x3) / F(2x2,3x3) + implicit GEMM; fp16-storage path: 16x16x32 MFMA)"; }
 
 int cid_create(cid_handle_t* out) {
     if (!out) return CID_ERR_INVALID;
