@@ -42,7 +42,7 @@ const char* kKernelNames[NL] = {
 const char* kHalfKernelNames[NL] = {
     "k_conv_head_h16", "k_conv3x3_h16<64, 64, 1,", "k_conv3x3_h16<64, 128, 0,", "k_conv3x3_h16<128, 128, 1,",
     "k_conv3x3_h16<128, 256, 0,", "k_conv3x3_h16<256, 256, 0,", "k_convt_t16<256, 128>", "k_conv3x3_h16<256, 128, 0,",
-    "k_conv3x3_h16<128, 128, 0,", "k_convt_t16<128, 64>", "k_conv3x3_h16<128, 64, 0, false>", "k_conv_tail_h<",
+    "k_conv3x3_h16<128, 128, 0,", "k_convt_t16<128, 64>", "k_conv3x3_h16<128, 64, 0, false,", "k_conv_tail_h<",
 };
 const char* kWino64KernelNames[NL] = {
     nullptr, "k_wino64_conv<64, 64, true,", "k_wino64_conv<64, 128, false,", "k_wino64_conv<128, 128, true,",
@@ -438,7 +438,10 @@ int env_wg_per_cu(const char* name, int dflt, int hi) {
     return v < 0 ? 0 : v > hi ? hi : v;
 }
 int g_wino42_wg_per_cu = env_wg_per_cu("CID_WINO42_WG_PER_CU", 2, 2);
-int g_half_wg_per_cu = env_wg_per_cu("CID_HALF_WG_PER_CU", 3, 3);   // k_conv3x3_h16, same meaning
+// k_conv3x3_h16, same meaning.  Default 0 since round 4: with the epilogue storing straight from the accumulators (no LDS staging, no barrier in front
+// of it) one workgroup per item is FASTER than three walkers per CU on every layer that walked — same box, three boxes: forward +2.3...+2.8 %, down1.2 -7...-8 %,
+// upconv1.0 -5.5...-6.7 %, upconv2.2 -2.6...-3.2 %, down2.2 -1.5...-2.6 % (profiles/r04_ab_f16_walk_vs_not.txt) — where round 3's kernels had gained 2.4 % from walking.
+int g_half_wg_per_cu = env_wg_per_cu("CID_HALF_WG_PER_CU", 0, 3);
 // CID_WINO42_XNB (environment, measurement aid): bit mask over the column-block counts NB (2, 4) whose walking launches give every XCD group ONE
 // column block (a.walk < 0, wino42_kernels.h) instead of walking all NB blocks of a tile back to back.  Default 0: profiles/r04_xnb_experiment.txt.
 int g_wino42_xnb = env_wg_per_cu("CID_WINO42_XNB", 0, 6);
@@ -590,7 +593,8 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
         if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
-        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT>), dim3(grid), dim3(THREADS), 0, s, a);
+        if (a.walk) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, true>), dim3(grid), dim3(THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, false>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();
 }
@@ -981,7 +985,7 @@ const char* cid_launch_name(int i) { return (i >= 0 && i < NL) ? kLayers[i].name
 const char* cid_launch_kernel(cid_handle_t h, int i) {
     if (i < 0 || i >= NL) return nullptr;
     if (h && h->dtype == CID_DTYPE_F16) {
-        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true>" : "k_conv_tail_zh<";
+        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true," : "k_conv_tail_zh<";
         return kHalfKernelNames[i];
     }
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];

@@ -365,7 +365,11 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     so an item's prologue (B DMA + halo request + their HBM latency, ~5-7k cycles beside 20-40k of work) is paid once per
 //     workgroup.  Everything renewed per item (B offset, halo offsets, image descriptor) is derived from per-item opaque values, or
 //     hipcc hoists it out of the item loop into registers this 168-register kernel does not have.
-template <int CIN, int COUT, int MODE, bool ZOUT = false>
+//   * (r4) WALK = false: the product's default form, one (tile, column block) item per workgroup — with the epilogue storing straight from the
+//     accumulators it measures faster than walking on every layer (profiles/r04_ab_f16_walk_vs_not.txt), and as a compile-time fact it removes the
+//     next-item decode, the prefetch under the last sub-step and the item boundary from the code.  WALK = true (cid_debug_half_workgroups_per_cu > 0)
+//     stays a tested option with the same bits.
+template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false>
 __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
 #ifndef CID_EXPERIMENTS
     static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
@@ -392,8 +396,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     __shared__ f32x4 lds[LDS_SLOTS];
 
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    int local = a.walk ? slot0 : slot0 / NB;                              // tile index inside the XCD group (k_wino42_conv)
-    int nb = a.walk ? 0 : slot0 - local * NB;
+    int local = (WALK && a.walk) ? slot0 : slot0 / NB;                    // tile index inside the XCD group (k_wino42_conv)
+    int nb = (WALK && a.walk) ? 0 : slot0 - local * NB;
     {
         const int mt = xcd * a.tiles_per_xcd + local;
         if (!(mt < a.tiles_total && local < a.tiles_per_xcd)) return;
@@ -461,7 +465,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     int n2, y02, x02, nb2, local2;
     auto decode_next = [&]() {
         n2 = n; y02 = y0; x02 = x0; local2 = local; nb2 = nb + 1;
-        has_next = a.walk != 0;
+        has_next = WALK && a.walk != 0;
         if (has_next && nb2 == NB) {
             nb2 = 0; local2 = local + a.walk;
             const int mt2 = xcd * a.tiles_per_xcd + local2;

@@ -43,9 +43,9 @@ void run(int N, int H, int W, bool zero, bool walk_ok) {
     CK(hipMalloc(&dtr, (size_t)grid * 64)); CK(hipMemset(dtr, 0, (size_t)grid * 64));
     a.pool = reinterpret_cast<_Float16*>(dtr);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, 0>), dim3(grid), dim3(THREADS), 0, 0, a);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, 0, false, true>), dim3(grid), dim3(THREADS), 0, 0, a);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, 0>), dim3(grid), dim3(THREADS), 0, 0, a);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, 0, false, true>), dim3(grid), dim3(THREADS), 0, 0, a);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
     std::vector<unsigned long long> tr((size_t)grid * 8);

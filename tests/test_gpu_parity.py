@@ -513,6 +513,8 @@ def test_walking_full_size_every_stage_bit_equal_and_stable(weight_sets, dtype):
     stages = ["down1", "pool1", "down2", "pool2", "bottleneck", "up2", "upconv2", "up1"]
     knob = L.cid_debug_winograd_workgroups_per_cu if dtype == "f32" else L.cid_debug_half_workgroups_per_cu
     prev = knob(-1)
+    walkers = prev if dtype == "f32" else 3      # fp16: one item per workgroup is the default since round 4; walking (3 per CU) is the option under test
+    assert walkers > 0
 
     def run(k):
         knob(k)
@@ -523,7 +525,7 @@ def test_walking_full_size_every_stage_bit_equal_and_stable(weight_sets, dtype):
     try:
         y0, s0 = run(0)
         for rep in range(3):
-            y1, s1 = run(prev)
+            y1, s1 = run(walkers)
             for s in stages:
                 assert torch.equal(s0[s], s1[s]), (rep, s, int((s0[s] != s1[s]).sum()))
             assert torch.equal(y0, y1), rep
@@ -532,7 +534,7 @@ def test_walking_full_size_every_stage_bit_equal_and_stable(weight_sets, dtype):
             # walk order over the same items, so the same bits at every stage
             assert L.cid_debug_winograd_column_block_per_xcd(6) == 0
             try:
-                y2, s2 = run(prev)
+                y2, s2 = run(walkers)
             finally:
                 assert L.cid_debug_winograd_column_block_per_xcd(0) == 6
             for s in stages:
@@ -557,12 +559,12 @@ def test_walking_workgroups_fp16_equal_one_item_per_workgroup(weight_sets):
     x, _, _ = synth.make_batch(37, 100, 76, first_index=8100)
     xd = torch.from_numpy(x).to("cuda:0")
     prev = L.cid_debug_half_workgroups_per_cu(-1)
-    assert prev == 3
+    assert prev == 0                                                  # the default since round 4: one item per workgroup
     try:
-        walk = m(xd).clone()
-        assert L.cid_debug_half_workgroups_per_cu(0) == 3
         one = m(xd).clone()
-        assert L.cid_debug_half_workgroups_per_cu(1) == 0
+        assert L.cid_debug_half_workgroups_per_cu(3) == 0
+        walk = m(xd).clone()
+        assert L.cid_debug_half_workgroups_per_cu(1) == 3
         single = m(xd).clone()
     finally:
         L.cid_debug_half_workgroups_per_cu(prev)
