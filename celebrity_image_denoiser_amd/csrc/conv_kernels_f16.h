@@ -358,7 +358,7 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     one tap column (12 KiB) at a time by LDS-DMA into one of two buffers — no staging registers, and the LDS stays under a
 //     third of the CU's; the halo tile of the next chunk waits in 24 registers over the chunk's last sub-step;
 //   * per sub-step the wave reads its four input rows once (8 A quads) and 12 B quads for 48 MFMAs.
-//   * (r3) walking workgroups, as k_wino42_conv: with more (tile, column block) items than three workgroups per CU the grid is what is
+//   * (r3; since r4 an option, not the default: see WALK below) walking workgroups, as k_wino42_conv: with more (tile, column block) items than three workgroups per CU the grid is what is
 //     resident and a workgroup walks tiles local, local + walk, ... of its XCD group, all NB column blocks of a tile back to back.
 //     Under the LAST sub-step of an item the next item's first B sub-chunk is fetched into B buffer 0 (free by then: the last
 //     sub-step reads buffer 1; the epilogue's staging starts behind buffer 0) and its first halo chunk into the 24 staging registers,
