@@ -237,7 +237,7 @@ def timed_forwards(model, x, steps, warmup):
     return elapsed, launch_ms, nfw, y
 
 
-def extra_config(model, sd_default, tag, B, S, dtype, steps=5, warmup=2):
+def extra_config(model, sd_default, tag, B, S, dtype, steps=20, warmup=5):
     """One of BASELINE.json's other single-GPU configs as a short leg of the default run (so the driver's record carries
     a number it timed itself): images/sec, slowest launch, parity spot check of the timed output against the CPU oracle."""
     from oracle import torch_oracle
