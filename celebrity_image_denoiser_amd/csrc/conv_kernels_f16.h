@@ -236,7 +236,7 @@ __device__ __forceinline__ void h16_store_row(int lane, V value, const __amdgpu_
             const int dp = (NPIX / 2) * pg + (NPIX == 32 ? (r & 1) + 4 * (r >> 1) : 2 * r);   // compile-time
             const f16x4 v = {(_Float16)value(pg, 0, r), (_Float16)value(pg, 1, r), (_Float16)value(pg, 2, r), (_Float16)value(pg, 3, r)};
             const unsigned vo = (!(H16_ABLATE & 4) && (full || (rowok && p0 + dp < xlim))) ? lane_off : 0x7ffffff0u;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, vo, row_off + (unsigned)(dp * stride * 2), /*nt*/ 2);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, vo, row_off + (unsigned)(dp * stride * 2), /*nt*/ 2);   // re-measured r4: plain stores -1.8 %
         }
 }
 
