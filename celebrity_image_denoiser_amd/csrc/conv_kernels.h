@@ -447,7 +447,7 @@ struct HeadArgs {
     int tiles_per_wg, groups_total, groups_per_xcd;   // a workgroup walks tiles_per_wg consecutive tiles (host: tile_groups)
     unsigned rcp_x, rcp_xy;   // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x*tiles_y)): division by multiply-high (host: tile_rcp)
 };
-// Host: tiles per workgroup of the head and tail kernels — 4 once there are enough tiles to fill the chip several times
+// Host: tiles per workgroup of the head and tail kernels — 8 / 4 once there are enough tiles to fill the chip several times
 // over, else 1 (small batches: more workgroups beat hidden latency).
 template <typename Args>
 inline void tile_groups(Args& a) {
