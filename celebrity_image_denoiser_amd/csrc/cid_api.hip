@@ -101,7 +101,7 @@ struct BlobLayout {
         }
         tab42_off[0] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);   // its LDS slot tables, TC = 8 and 4
         tab42_off[1] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
-        hz_off = o; o = align_up(o + 3 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused last layer: upconv1[2] as A fragments [3 row tiles][2 k-steps][64 lanes][8] halfs
+        hz_off = o; o = align_up(o + 3 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused last layer: upconv1[2] as A fragments [2 row tiles][2 k-steps][64 lanes][8] halfs (room for three, as round 4's first form had)
         total = o;
     }
 };
@@ -758,12 +758,12 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                 const int col = (kh * 3 + kw) * 3 + co, s = ci >> 4, hh = (ci >> 3) & 1, e = ci & 7;
                 hd[((size_t)s * 64 + hh * 32 + col) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
-            // and for the fused form (h16_zout_epilogue): the A operand of z^T = W2' . X^T on v_mfma_f32_16x16x32_f16, row 4 tap + co
-            // (co = 3 and rows 36..47 stay zero): [row tile t][k-step ks][lane = 16 kga + row][e] with ci = 32 ks + 8 kga + e
+            // and for the fused form (h16_zout_epilogue): the A operand of z^T = W2' . X^T on v_mfma_f32_16x16x32_f16, row 3 tap + co
+            // (27 rows, rows 27..31 stay zero): [row tile t][k-step ks][lane = 16 kga + row][e] with ci = 32 ks + 8 kga + e
             _Float16* hz = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.hz_off);
             std::memset(hz, 0, 3 * 2 * 64 * 8 * sizeof(_Float16));
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
-                const int row = 4 * (kh * 3 + kw) + co, t = row >> 4, ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
+                const int row = 3 * (kh * 3 + kw) + co, t = row >> 4, ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
                 hz[(((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
         }
@@ -1183,9 +1183,9 @@ int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops
     const double px = (double)N * d.Hu1 * d.Wu1;
     double f11, b11;
     cid_launch_work(11, N, H, W, &f11, &b11);
-    // z elements per pixel: 27 fp32 planes; on the fp16-storage path 9 taps x 4 halfs (three channels and a pad), counted here in
+    // z elements per pixel: 27 fp32 planes; on the fp16-storage path 7 groups x 4 halfs (27 rows and a pad), counted here in
     // fp32-sized elements like every other activation of that path (bench.py halves the bytes between the first and the last tensor)
-    const double zc = h->dtype == CID_DTYPE_F16 ? 36 : 27;
+    const double zc = h->dtype == CID_DTYPE_F16 ? 28 : 27;
     if (i == 10) {
         *flops += f11;
         *bytes += 4.0 * px * (zc - 64) + 4.0 * ref_weight_count(kLayers[11]);

@@ -277,15 +277,18 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4
 // round 2 (wino42_kernels.h, ZOUT): upconv1[2] = Conv2d(64, 3, 3, padding=1) (app.py:77) is a 1x1 contraction per tap followed by a
 // nine-tap shifted sum, and the contraction has no halo — so it runs HERE, on the wave's finished 2 rows x 32 pixels x 64 channels, and
 // the 64-channel tensor (128 B per pixel written, then re-read with a 10x34 / 8x32 halo by k_conv_tail_h) never exists:
-//     z[n][tap][y][x][co] = sum_ci half(relu(upconv1.0))[n][y][x][ci] * W2[co][ci][tap]            72 B per pixel (9 taps x 4 halfs: co 0..2, one pad)
+//     z[n][row = 3 tap + co][y][x] = sum_ci half(relu(upconv1.0))[n][y][x][ci] * W2[co][ci][tap]   56 B per pixel: 27 rows + 1 pad = 7 groups of 4 halfs
+//     (first form of round 4: row 4 tap + co, 9 groups = 72 B per pixel and three row tiles of MFMAs)
 // The activation is rounded to half exactly as the stored tensor was, so only z's own rounding to half is new (CPU emulation of the
 // whole path, He-gain weights, 16 images: 3.2e-3 against 3.4e-3 unfused, z half vs unfused 8.9e-4; tools/emulate_f16_zout.py).
 //   * the wave's pixels go to a wave-private LDS area [row][pixel][8 slots of 8 channels], slot XOR (pixel & 7): a lane's four
 //     consecutive channels are one ds_write_b64 (16 lanes = one pixel's 128 B: conflict-free), and the B operand of the z product —
 //     lane (column = pixel, k-group) = 8 consecutive channels — one ds_read_b128 (conflict-free by the XOR, checked exhaustively);
-//   * z^T = W2' . X^T on v_mfma_f32_16x16x32_f16 with the WEIGHTS as rows: row 4 tap + co (36 of 48 rows used: three row tiles),
-//     K = 64 channels = two steps -> 24 MFMAs per wave beside the 576 of the main loop; a lane of the result holds the four `co`
-//     of ONE (tap, pixel): 8 bytes as halfs, stored straight from registers (16 lanes = 16 consecutive pixels of a tap plane).
+//   * z^T = W2' . X^T on v_mfma_f32_16x16x32_f16 with the WEIGHTS as rows: row 3 tap + co (27 of 32 rows used: two row tiles),
+//     K = 64 channels = two steps -> 16 MFMAs per wave beside the 576 of the main loop; a lane of the result holds four consecutive
+//     rows of ONE pixel = one group: 8 bytes as halfs, stored straight from registers (16 lanes = 16 consecutive pixels of a group plane).
+// the fused last layer's partial sums: 27 rows (3 tap + co) + 1 pad per pixel as 7 groups of four halfs, z[n][group][y][x][4]
+constexpr int Z_GROUPS = 7;
 template <typename Args>
 __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0,
                                                   int wave, int lane) {
@@ -304,9 +307,9 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
                 *reinterpret_cast<f16x4*>(stg + ((m * 32 + P) * 8 + ((c16 >> 1) ^ (P & 7))) * 16 + (c16 & 1) * 8) = v;
             }
     // the last layer's weights are requested only now, with the accumulators dead (24 registers; an L2 hit per item)
-    f16x8 wz[3][2];
+    f16x8 wz[2][2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wz[t][ks] = reinterpret_cast<const f16x8*>(a.pool)[(t * 2 + ks) * 64 + lane];
     wave_lds_fence();
@@ -322,13 +325,13 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
             const int y = y0 + 2 * wave + m, x = x0 + P;
             const bool inside = y < a.Hs && x < a.Ws;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wz[t][0], xb[0], zero, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wz[t][1], xb[1], z, 0, 0, 0);
-                const int tap = 4 * t + kg;                                               // rows 4 kg + r of row tile t: tap 4 t + kg, co = r
+                const int grp = 4 * t + kg;                                               // rows 16 t + 4 kg + r = 3 tap + co: row group 4 t + kg of the 7 (Z_GROUPS) a pixel has
                 const f16x4 hz = {(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
-                if (inside && tap < 9) *reinterpret_cast<f16x4*>(a.out + ((((size_t)n * 9 + tap) * plane + (size_t)y * a.Ws + x) << 2)) = hz;
+                if (inside && grp < Z_GROUPS) *reinterpret_cast<f16x4*>(a.out + ((((size_t)n * Z_GROUPS + grp) * plane + (size_t)y * a.Ws + x) << 2)) = hz;
             }
         }
 }
@@ -889,11 +892,11 @@ __global__ void __launch_bounds__(THREADS, 2) k_conv_tail_h(const TailArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Tail of the fp16-storage path, fused form (round 4; default): k_conv3x3_h16<128, 64, 0, ZOUT> has contracted the 64 channels,
-// z[n][tap][y][x][4 halfs].  What is left of upconv1[2] + tanh (app.py:77,103) is the nine-tap shifted sum, as in k_conv_tail_z:
-//     out[n][co][y][x] = tanh(bias[co] + sum_{ty,tx} z[n][3 ty + tx][y+ty-1][x+tx-1][co])        (zero outside the image)
-// One thread per pixel, NINE 8-byte loads (a tap's three channels travel together; consecutive lanes = consecutive pixels = 512
-// contiguous bytes per wave instruction; out-of-image taps carry an out-of-range per-lane offset), fp32 sums in tap order, three
-// tanhf.  HBM-bound on 84 B per pixel (72 z + 12 out) where k_conv_tail_h moved 140 with a halo on top.
+// z[n][group][y][x][4 halfs] with row 3 tap + co = 4 group + slot.  What is left of upconv1[2] + tanh (app.py:77,103) is the nine-tap shifted sum, as in k_conv_tail_z:
+//     out[n][co][y][x] = tanh(bias[co] + sum_{ty,tx} z[n][3 (3 ty + tx) + co][y+ty-1][x+tx-1])        (zero outside the image)
+// One thread per pixel, THIRTEEN 8-byte loads (a tap's three rows lie in one group or straddle two: taps 0, 3, 4, 7, 8 one load, the others two;
+// consecutive lanes = consecutive pixels = 512 contiguous bytes per wave instruction; out-of-image taps carry an out-of-range per-lane offset),
+// fp32 sums in tap order, three tanhf.  HBM-bound on 68 B per pixel (56 z + 12 out) where the 9-group form moved 84 and k_conv_tail_h 140 with a halo on top.
 template <bool OUT_U8>
 __global__ void __launch_bounds__(THREADS) k_conv_tail_zh(const TailZArgs a) {
     const unsigned b = blockIdx.x;
@@ -902,9 +905,9 @@ __global__ void __launch_bounds__(THREADS) k_conv_tail_zh(const TailZArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     const unsigned y = a.rcp_w ? __umulhi(p, a.rcp_w) : p, x = p - y * a.W;
     const bool inside = p < plane;
-    // descriptor over the image's 9 tap planes of 8 bytes per pixel (<= 302 MB: H*W < 4,194,303, cid_api.hip shape_error)
-    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const _Float16*>(a.z) + (size_t)n * 36 * plane), (short)0,
-                                                                        (int)(plane * 72), 0x00020000);
+    // descriptor over the image's 7 group planes of 8 bytes per pixel (<= 235 MB: H*W < 4,194,303, cid_api.hip shape_error)
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const _Float16*>(a.z) + (size_t)n * (4 * Z_GROUPS) * plane), (short)0,
+                                                                        (int)(plane * (8 * Z_GROUPS)), 0x00020000);
     float o[3] = {a.bias[0], a.bias[1], a.bias[2]};
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty)
@@ -912,10 +915,13 @@ __global__ void __launch_bounds__(THREADS) k_conv_tail_zh(const TailZArgs a) {
         for (int tx = 0; tx < 3; ++tx) {
             const int yy = (int)y + ty - 1, xx = (int)x + tx - 1;
             const bool ok = inside && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)((yy * a.W + xx) * 8) : 0x7ffffff0u;   // the mask lives in the per-lane offset; the tap plane is the scalar one
-            const f16x4 hv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rz, off, (int)((3 * ty + tx) * plane * 8), 0));
+            const unsigned off = ok ? (unsigned)((yy * a.W + xx) * 8) : 0x7ffffff0u;   // the mask lives in the per-lane offset; the group plane is the scalar one
+            const int r0 = 3 * (3 * ty + tx), g0 = r0 >> 2, g1 = (r0 + 2) >> 2;       // compile-time after unrolling
+            const f16x4 v0 = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rz, off, (int)(g0 * plane * 8), 0));
+            f16x4 v1 = v0;
+            if (g1 != g0) v1 = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rz, off, (int)(g1 * plane * 8), 0));
 #pragma unroll
-            for (int co = 0; co < 3; ++co) o[co] += (float)hv[co];
+            for (int co = 0; co < 3; ++co) o[co] += (float)(((r0 + co) >> 2) == g0 ? v0 : v1)[(r0 + co) & 3];
         }
     const int cy = (int)y - a.crop.top, cx = (int)x - a.crop.left;   // the caller's tensor
     if (!inside || (unsigned)cy >= (unsigned)a.crop.H || (unsigned)cx >= (unsigned)a.crop.W) return;

@@ -201,8 +201,8 @@ int cid_get_conv_algo(cid_handle_t h, int* algo);
  * How the last layer (upconv1[2] = Conv2d(64,3,3,p=1) + tanh, backend/app.py:77,103) runs on the fp32 path; same function:
  *   CID_TAIL_FUSED  (default) its 64 -> 27 (tap x channel) contraction runs in the epilogue of upconv1[0]'s kernel, on the
  *                   tile still in LDS; the last launch is the nine-tap shifted sum + bias + tanh over 27 fp32 planes (CID_DTYPE_F32; needs
- *                   a Winograd algorithm, with CID_ALGO_DIRECT the handle behaves as CID_TAIL_BANDS) or over 9 tap planes of 4 halfs
- *                   (CID_DTYPE_F16, round 4).
+ *                   a Winograd algorithm, with CID_ALGO_DIRECT the handle behaves as CID_TAIL_BANDS) or over 7 planes of 4 halfs (the same 27
+ *                   rows 3 tap + co and a pad; CID_DTYPE_F16, round 4).
  *   CID_TAIL_BANDS  separate kernel: a workgroup slides down a band of rows, the contraction is computed once per pixel
  *                   (images up to 128 pixels wide, wider ones take CID_TAIL_TILES)
  *   CID_TAIL_TILES  separate kernel: 8x32-pixel tiles, the contraction is computed over each tile's halo (round 1's kernel)
