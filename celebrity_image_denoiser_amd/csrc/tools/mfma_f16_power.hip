@@ -120,6 +120,58 @@ void run32(const char* name, const f32x4* src, float* out, double seconds) {
     std::fflush(stdout);
 }
 
+// The wave tile priced in DESIGN.md section 5 (128 pixels x 64 channels): 32 accumulator tiles (128 registers), two waves per SIMD, per step
+// 12 "A" + 12 "B" operand quads for 96 MFMAs of 16x16x32 — 0.25 ds_read_b128 per MFMA instead of 0.42
+template <int LDSQ>
+__global__ void __launch_bounds__(256, 2) k_f16_wide(const f32x4* src, float* out, int steps) {
+    __shared__ f32x4 lds[2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 2048; i += 256) lds[i] = src[i];
+    __syncthreads();
+    f32x4 q[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) q[i] = lds[(i * 64 + lane * 5) & 2047];
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; ++s) {
+        if (LDSQ) {
+#pragma unroll
+            for (int i = 0; i < LDSQ; ++i) q[i] = lds[((s * 7 + i) * 64 + lane) & 2047];
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, q[(t & 7) + (dy & 1) * 4]), __builtin_bit_cast(f16x8, q[12 + dy * 4 + (t >> 3)]), acc[t], 0, 0, 0);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + tid] = r;
+}
+
+template <int LDSQ>
+void run_wide(const char* name, const f32x4* src, float* out, double seconds) {
+    const int grid = 256 * 2 * 8, steps = 450;
+    hipLaunchKernelGGL((k_f16_wide<LDSQ>), dim3(grid), dim3(256), 0, 0, src, out, steps);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double first = 0, last = 0; int n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((k_f16_wide<LDSQ>), dim3(grid), dim3(256), 0, 0, src, out, steps);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        const double tf = (double)grid * 4 * steps * 96 * 16384.0 * 50 / (t * 1e-3) / 1e12;
+        if (n == 0) first = tf;
+        last = tf; ++n;
+    }
+    std::printf("%-44s first 50 launches %7.1f TFLOP/s   settled (after %.1f s) %7.1f TFLOP/s  = %.3f of 2,500\n", name, first, seconds, last, last / 2500.0);
+    std::fflush(stdout);
+}
+
 template <int SHAPE, int LDSQ>
 void run(const char* name, const f32x4* src, float* out, double seconds) {
     const int grid = 256 * 3 * 8, steps = 600;             // 8 rounds of three workgroups per CU, ~0.3 ms per launch
@@ -157,6 +209,8 @@ int main(int argc, char** argv) {
     run<1, 20>("32x32x16 f16 + 20 ds_read_b128 per 24", src, out, sec);
     run<0, 10>("16x16x32 f16 + 10 ds_read_b128 per 48", src, out, sec);
     run<0, 0>("16x16x32 f16, registers only (again)", src, out, sec);
+    run_wide<24>("16x16x32 f16, 128 acc, 2 waves/SIMD, 24 reads/96", src, out, sec);
+    run_wide<0>("16x16x32 f16, 128 acc, 2 waves/SIMD, registers", src, out, sec);
     run32<0, 0>("16x16x4 f32, registers only", src, out, sec);
     run32<60, 0>("16x16x4 f32 + 60 v_fma per 48 (1.26/MFMA)", src, out, sec);
     run32<60, 16>("16x16x4 f32 + 60 v_fma + 16 ds_read_b64", src, out, sec);
