@@ -1172,14 +1172,20 @@ int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes) {
     return CID_OK;
 }
 
-// The same per LAUNCH under the handle's configuration.  It differs from the per-layer figures only when the last layer's
+// The same per LAUNCH under the handle's configuration.  It differs from the per-layer figures (a) on launches 1 and 3, which write the pooled
+// tensor beside their own output (the reference's MaxPool2d modules are fused into them), and (b) when the last layer's
 // channel contraction is fused into upconv1[0]'s launch (CID_TAIL_FUSED): launch 10 then carries the FLOPs of both layers and
 // writes 27 z planes instead of 64 channels; launch 11 is the shifted sum (no multiply-adds) over those planes.
 int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops, double* bytes) {
     const int rc = cid_launch_work(i, N, H, W, flops, bytes);
-    if (rc != CID_OK || !h || !fused_tail_active(h) || i < 10) return rc;
+    if (rc != CID_OK) return rc;
     Dims d;
     make_dims(N, H, W, d);
+    // launches 1 and 3 (down1[2], down2[2]) also write the 2x2-pooled tensor from their epilogue (pool1 / pool2, app.py:48,56: SURVEY 8a rows a3 / a6 —
+    // the pools' reads are what the fusion removes, their writes remain): in every configuration of the handle
+    if (i == 1) *bytes += 4.0 * N * (double)d.H1 * d.W1 * kLayers[1].cout;
+    if (i == 3) *bytes += 4.0 * N * (double)d.H2 * d.W2 * kLayers[3].cout;
+    if (!h || !fused_tail_active(h) || i < 10) return rc;
     const double px = (double)N * d.Hu1 * d.Wu1;
     double f11, b11;
     cid_launch_work(11, N, H, W, &f11, &b11);

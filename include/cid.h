@@ -213,7 +213,8 @@ int cid_get_tail_algo(cid_handle_t h, int* algo);
 /* Algorithmic work of the i-th launch for an [N,3,H,W] forward: conv/convT FLOPs (2*MAC) and
  * fp32 bytes (input activations + output activations + weights, each once) — SURVEY.md 8(a). */
 int cid_launch_work(int i, int N, int H, int W, double* flops, double* bytes);
-/* The same per LAUNCH under the handle's configuration: identical except with CID_TAIL_FUSED, where launch 10 also carries
+/* The same per LAUNCH under the handle's configuration: launches 1 and 3 also count the 2x2-pooled tensor they write (pool1 / pool2,
+ * backend/app.py:48,56, run in their epilogues: SURVEY.md 8(a) rows a3 / a6 less the pools' reads); with CID_TAIL_FUSED launch 10 also carries
  * upconv1[2]'s FLOPs and writes 27 planes instead of 64 channels, and launch 11 only sums, adds the bias and applies tanh. */
 int cid_launch_work_ex(cid_handle_t h, int i, int N, int H, int W, double* flops, double* bytes);
 
