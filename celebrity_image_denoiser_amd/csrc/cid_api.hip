@@ -593,8 +593,13 @@ hipError_t launch_gemm_h(hipStream_t s, const float* blob, int layer, const void
         int grid = 8 * g.per_xcd * NB;
         const int walkers = g_half_wg_per_cu * device_cus() / 8;
         if (CIN <= 128 && g_half_wg_per_cu > 0 && walkers >= 1 && grid > 8 * walkers && g.per_xcd >= walkers) { a.walk = walkers; grid = 8 * walkers; }   // >= one tile per walker, as in wino42_grid
-        if (a.walk) hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, true>), dim3(grid), dim3(THREADS), 0, s, a);
-        else hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, false>), dim3(grid), dim3(THREADS), 0, s, a);
+        // the pooling launches (MODE 1) never walk: their walking variants were the last kernels of the library with spilled registers (4 VGPRs, 20 B of
+        // scratch per lane) and walking is slower than one item per workgroup on them by the widest margin (-7...-10 % on down1.2)
+        if constexpr (MODE == 0) {
+            if (a.walk) { hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, true>), dim3(grid), dim3(THREADS), 0, s, a); return hipGetLastError(); }
+        }
+        a.walk = 0; grid = 8 * g.per_xcd * NB;
+        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, ZOUT, false>), dim3(grid), dim3(THREADS), 0, s, a);
     }
     return hipGetLastError();
 }

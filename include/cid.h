@@ -268,7 +268,8 @@ int cid_debug_winograd_workgroups_per_cu(int k);
  * -3 % fabric traffic, +-0 time).  Returns the previous mask; a negative argument only queries. */
 int cid_debug_winograd_column_block_per_xcd(int mask);
 /* The same for the 3x3 launches of the fp16-storage path (k_conv3x3_h16): k walking workgroups per CU (at most 3), 0 = one item per workgroup — the
- * DEFAULT since round 4 (measured faster once the epilogue lost its LDS staging: profiles/r04_ab_f16_walk_vs_not.txt); walking stays a tested option. */
+ * DEFAULT since round 4 (measured faster once the epilogue lost its LDS staging: profiles/r04_ab_f16_walk_vs_not.txt); walking stays a tested option for the
+ * launches without a fused pool (down1[2] and down2[2] always take one item per workgroup). */
 int cid_debug_half_workgroups_per_cu(int k);
 
 #ifdef __cplusplus
