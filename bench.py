@@ -25,6 +25,9 @@ Extra objects on that line:
   configs       (N=1 only) short legs at BASELINE.json configs[3] (B=256, 256x256, fp32) and configs[4] (B=512, fp16
                 storage): images/sec, slowest launch, parity spot check
   hot_weights_leg, dist_world1_leg  (N=1 only) 5 steps on the He-gain weight set; RCCL communicator + weights broadcast at world size 1
+  rccl, parity.max_abs_err_all_ranks  (N>1, or --force-dist) what RCCL reports for the weights communicator and the one broadcast; the worst
+                error over ALL ranks of two images of each rank's own shard against the CPU oracle (ranks > 0 run on the broadcast weights)
+  rehearsal     only with --rehearse-shared-gpu: the N>1 code path with all ranks on cuda:0 over gloo (one-GPU boxes); not a scaling number
   cpu_baseline  (N=1 only) the CPU oracle = the reference's forward re-stated on the ATen CPU
                 operators the reference itself calls, timed on this host's cores on a bounded sample
 """
@@ -286,6 +289,9 @@ def main():
                     help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path on a 1-GPU box")
     ap.add_argument("--self-launch", action="store_true",
                     help="go through the rank launcher even with --gpus 1 (rehearses launcher -> child -> relay on a 1-GPU box)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL of the N>1 code path on a box with fewer GPUs than ranks: every rank uses cuda:0 and the process group runs on gloo "
+                         "(RCCL refuses two ranks on one device, so the blob travels by the fallback transport); the line is marked and is not a scaling number")
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.self_launch) and "WORLD_SIZE" not in os.environ:
@@ -312,7 +318,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.rehearse_shared_gpu else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
@@ -320,7 +326,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, S = args.batch_per_gpu, args.size
     sd = synth.make_state_dict(args.weights)
@@ -358,10 +367,23 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms, nfw = model.timing_end()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_shared_gpu else dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    err_all_ranks = None
+    if use_dist:
+        # every rank checks the first two images of ITS shard against the CPU oracle (untimed): a rank other than 0 can only pass with the
+        # weights the broadcast delivered (it started from its own random init); the worst error over the ranks goes into the line
+        try:
+            from oracle import torch_oracle
+
+            e = float(np.abs(y[:2].cpu().numpy() - torch_oracle.forward(sd, x_host[:2]).numpy()).max())
+        except Exception:  # pragma: no cover
+            e = float("nan")
+        et = torch.tensor([e if e == e else 1e30], dtype=torch.float64, device=t.device)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        err_all_ranks = float(et.item())
 
     if rank == 0:
         table = launch_table(end - begin, S, S, model)
@@ -393,6 +415,9 @@ def main():
             res["rccl"] = {"nranks": bcast["nranks"], "transport": bcast["transport"], "broadcast_ms": round(bcast["broadcast_ms_cached_comm"], 3),
                            "first_broadcast_ms": round(bcast["broadcast_ms"], 3), "comm_setup_ms": round(bcast["setup_ms"], 2),
                            "blob_bytes": int(model.pack_weights().numel()), "collectives_in_forward": 0}
+        if args.rehearse_shared_gpu:
+            res["rehearsal"] = (f"{world} ranks SHARING cuda:0 over gloo: exercises launcher, sharding, barrier, max-over-ranks timing and the aggregate; "
+                                "not a scaling measurement, and no RCCL (two ranks on one device are refused)")
         # parity spot-check on the timed output: 2 images vs the CPU oracle
         try:
             from oracle import torch_oracle
@@ -403,6 +428,8 @@ def main():
                              "psnr_delta_db": abs(cid.psnr(got, clean_host[:2]) - cid.psnr(ref, clean_host[:2])),
                              "tolerance": "max|delta|<=1e-5, psnr_delta<=0.01 dB" if not f16 else
                                           "fp16 storage: max|delta|<=5e-4 at default weight scale (tests/test_gpu_parity.py)"}
+            if err_all_ranks is not None:
+                res["parity"]["max_abs_err_all_ranks"] = err_all_ranks     # ranks > 0 run on the broadcast weights
         except Exception as e:  # pragma: no cover
             res["parity"] = {"error": str(e)[:200]}
         if args.no_extras:
