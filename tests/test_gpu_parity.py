@@ -803,6 +803,27 @@ def test_graphed_forward_survives_arena_growth_and_new_weights(weight_sets):
     assert torch.equal(fast(x1), want_hot)                   # noticed the new blob and re-captured
 
 
+def test_bench_two_ranks_sharing_the_gpu():
+    """The N > 1 path of bench.py with REAL GPU processes on a one-GPU box (`--rehearse-shared-gpu`: both ranks on cuda:0, gloo): the plain
+    command starts its own ranks, they rendezvous, RCCL's set-up is refused on both (two ranks on one device) and the agreed fallback transport
+    carries the blob, each rank runs its shard, and rank 0's single line reports the aggregate and the worst oracle error over BOTH ranks —
+    rank 1 started from its own random init, so it passes only on the broadcast weights (backend/app.py:80-103 is the shard unit)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--batch-per-gpu", "8", "--steps", "2", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]                            # ONE line on stdout, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and "rehearsal" in d and d["scaling"] == "weak"
+    assert d["rccl"]["collectives_in_forward"] == 0 and d["rccl"]["transport"] in ("torch-distributed", "rccl-cabi")
+    assert d["parity"]["max_abs_err_all_ranks"] <= 1e-5 and d["parity"]["max_abs_err_vs_cpu_oracle"] <= 1e-5
+    assert d["value"] == pytest.approx(16 * 2 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-3)     # whole-job images over the max-over-ranks time
+
+
 def test_rccl_broadcast_through_the_c_abi(weight_sets):
     """the one collective of the multi-GPU job is `cid_broadcast_weights` — ncclBroadcast issued by
     libcid.so on a communicator made with cid_comm_* — here on the world this box has (one rank).  The receiver's
