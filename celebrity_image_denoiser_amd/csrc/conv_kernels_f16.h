@@ -257,6 +257,10 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4
             const int y = __builtin_amdgcn_readfirstlane(y0 + 2 * wave + m);
             const unsigned row_off = (unsigned)(((y * a.Ws + x0) * a.out_ps + a.out_coff + cobase) * 2);
             h16_store_row<32>(lane, [&](int pg, int cg, int r) { return fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); }, ro, row_off, a.out_ps, a.Ws - x0, y < a.Hs, full);
+#ifdef H16_SPLIT_OUT   // experiment (csrc/tools/split_proto, -DCID_EXPERIMENTS): the fp32 result kept as TWO halfs — hi = half(v) at channel c (above), lo = half(v - hi) at channel out_ps / 2 + c
+            h16_store_row<32>(lane, [&](int pg, int cg, int r) { const float v = fmaxf(acc[m][pg][cg][r] + bias_v[cg], 0.f); return v - (float)(_Float16)v; }, ro,
+                              row_off + (unsigned)a.out_ps, a.out_ps, a.Ws - x0, y < a.Hs, full);
+#endif
         }
     }
     if (MODE == 1) {   // 2x2 max-pool, floor mode: registers (r, r+1), r even, of the wave's two rows are one window
