@@ -15,6 +15,9 @@
 #pragma once
 #include "conv_kernels.h"
 
+#if (defined(H16_SPLIT_IN) || defined(H16_SPLIT_OUT)) && !defined(CID_EXPERIMENTS)
+#error "the split-operand prototype is built only by csrc/tools (-DCID_EXPERIMENTS)"
+#endif
 #ifndef H16_ABLATE   // timing / energy experiments of csrc/tools/h16_trace only (wrong results when non-zero): 1 no B DMA after a workgroup's first item,
 #define H16_ABLATE 0  // 2 no halo loads after the first item, 4 no stores, 8 fragments read from LDS once per item (MFMAs on stale registers)
 #endif
@@ -606,6 +609,30 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 #ifdef H16_TRACE
         tr_lap(tr_bnd);     // prologue of the first item / boundary of the later ones
 #endif
+#ifdef H16_SPLIT_IN
+        {   // experiment (csrc/tools/split_proto, -DCID_EXPERIMENTS): split-operand fp32 convolution.  A pixel holds [hi | lo] halfs of C = CIN / 2 fp32 channels, the packed
+            // weights [hi_w | lo_w] as 2 C input channels.  Halo chunk ck < NCH (hi_x) runs SIX sub-steps — its three tap columns against hi_w, then against lo_w, from the same
+            // fragments — and chunk NCH + c (lo_x) three against hi_w: 9 NCH sub-steps.  Sub-step s reads B buffer s & 1 and requests the sub-chunk of step s + 1 into the other one;
+            // which packed sub-chunk that is goes through `wbase` (dma_b fetches wbase + (s + 1) sub-chunks).
+            static_assert(!WALK && !ZOUT && NCHUNK % 2 == 0, "prototype: one item per workgroup, plain epilogue");
+            constexpr int NCH = NCHUNK / 2, NSEQ = 9 * NCH;
+            const int wbase0 = wbase;
+            auto packed_of = [&](int q) { if (q < 6 * NCH) { const int c = q / 6, j = q - 6 * c; return j < 3 ? 3 * c + j : 3 * (NCH + c) + j - 3; } return q - 6 * NCH; };
+            auto aim = [&](int q) { wbase = wbase0 + (packed_of(q + 1) - (q + 1)) * (BSUB * 16); };
+            aim(0); substep(T{}, F{}, 0, 0); seam();
+            for (int q = 1; q < NSEQ - 1; ++q) {
+                int ck, j, nsub;
+                if (q < 6 * NCH) { ck = q / 6; j = q - 6 * ck; nsub = 6; } else { const int t = q - 6 * NCH; ck = NCH + t / 3; j = t - 3 * (t / 3); nsub = 3; }
+                const int dx = j >= 3 ? j - 3 : j;
+                const int req = (j == nsub - 2 && ck + 1 < NCHUNK) ? ck + 1 : -1;
+                aim(q);
+                substep(F{}, F{}, q, dx, req);
+                if (j == nsub - 1) chunk_seam(); else if (req >= 0) seam_keep_halo(); else seam();
+            }
+            wbase = wbase0;
+            substep(F{}, T{}, NSEQ - 1, 2);
+        }
+#else
         substep(T{}, F{}, 0, 0); seam();
         substep(F{}, F{}, 1, 1, 1); seam_keep_halo();
         substep(F{}, F{}, 2, 2); chunk_seam();
@@ -617,6 +644,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         substep(F{}, F{}, NSUB - 3, 0); seam();
         substep(F{}, F{}, NSUB - 2, 1); seam();
         substep(F{}, T{}, NSUB - 1, 2);
+#endif
 
 #ifdef H16_TRACE
         asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));

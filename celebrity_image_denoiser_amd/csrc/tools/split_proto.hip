@@ -7,6 +7,8 @@
 //      power-of-two weight scale that keeps lo_w a normal half (does the MFMA honour fp16 denormals?);
 //   2. time: the eight 3x3 layer shapes of the network at B = 256, beside the fp32 Winograd launches of profiles/r04_final_bench.json.
 //   hipcc -O3 -std=c++17 -fno-slp-vectorize -DCID_EXPERIMENTS -DH16_SPLIT_OUT --offload-arch=gfx950 -o tools/split_proto tools/split_proto.hip
+// Second form, -DH16_SPLIT_IN as well (tools/split_proto2): the kernel's own split sequencing (conv_kernels_f16.h) — a pixel holds [hi_x | lo_x] (2 CIN halfs = the
+// bytes of the fp32 tensor), the weights [hi_w | lo_w]; a hi chunk's fragments serve six sub-steps (hi_w, then lo_w), a lo chunk's three (hi_w).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -17,6 +19,11 @@
 #include "../conv_kernels.h"
 #include "../conv_kernels_f16.h"
 using namespace cid;
+#ifdef H16_SPLIT_IN
+constexpr int CMUL = 2;      // half channels per fp32 channel in the input tensor and in the packed weights
+#else
+constexpr int CMUL = 3;
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 // the product's weight layout for k_conv3x3_h16 (cid_api.hip packed_index_h16), restated for a layer of `cin` input channels
@@ -56,12 +63,13 @@ static void numerics(float wscale_log2) {
     for (auto& v : w) v = 0.06f * u(rng);
     for (auto& v : b) v = 0.1f * u(rng);
     const float s = std::ldexp(1.f, (int)wscale_log2);
-    std::vector<_Float16> hin((size_t)N * H * W * 3 * C), hw((size_t)K * 3 * C * 9);
+    std::vector<_Float16> hin((size_t)N * H * W * CMUL * C), hw((size_t)K * CMUL * C * 9);
     for (size_t p = 0; p < (size_t)N * H * W; ++p)
         for (int c = 0; c < C; ++c) {
             const float v = x[p * C + c];
             const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-            hin[p * 3 * C + c] = hi; hin[p * 3 * C + C + c] = hi; hin[p * 3 * C + 2 * C + c] = lo;
+            if (CMUL == 3) { hin[p * 3 * C + c] = hi; hin[p * 3 * C + C + c] = hi; hin[p * 3 * C + 2 * C + c] = lo; }
+            else { hin[p * 2 * C + c] = hi; hin[p * 2 * C + C + c] = lo; }
         }
     int lo_subnormal = 0;
     for (int co = 0; co < K; ++co)
@@ -71,7 +79,8 @@ static void numerics(float wscale_log2) {
                     const float v = w[(((size_t)co * C + ci) * 3 + kh) * 3 + kw] * s;
                     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
                     if (lo != (_Float16)0.f && std::fabs((float)lo) < 6.104e-5f) ++lo_subnormal;
-                    hw[packed_index(3 * C, co, ci, kh, kw)] = hi; hw[packed_index(3 * C, co, C + ci, kh, kw)] = lo; hw[packed_index(3 * C, co, 2 * C + ci, kh, kw)] = hi;
+                    hw[packed_index(CMUL * C, co, ci, kh, kw)] = hi; hw[packed_index(CMUL * C, co, C + ci, kh, kw)] = lo;
+                    if (CMUL == 3) hw[packed_index(3 * C, co, 2 * C + ci, kh, kw)] = hi;
                 }
     std::vector<float> bs(K);
     for (int k = 0; k < K; ++k) bs[k] = b[k] * s;
@@ -79,7 +88,7 @@ static void numerics(float wscale_log2) {
     CK(hipMalloc(&din, hin.size() * 2)); CK(hipMalloc(&dw, hw.size() * 2)); CK(hipMalloc(&dout, (size_t)N * H * W * 2 * K * 2)); CK(hipMalloc(&db, K * 4));
     CK(hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, bs.data(), K * 4, hipMemcpyHostToDevice));
-    launch<3 * C, K>(din, dw, db, dout, N, H, W);
+    launch<CMUL * C, K>(din, dw, db, dout, N, H, W);
     CK(hipDeviceSynchronize());
     std::vector<_Float16> hout((size_t)N * H * W * 2 * K);
     CK(hipMemcpy(hout.data(), dout, hout.size() * 2, hipMemcpyDeviceToHost));
@@ -111,7 +120,7 @@ static void numerics(float wscale_log2) {
 
 template <int CIN, int COUT>
 static void timing(const char* layer, int N, int H, int W, double wino_ms) {
-    constexpr int C3 = 3 * CIN;
+    constexpr int C3 = CMUL * CIN;
     const size_t in_n = (size_t)N * H * W * C3, out_n = (size_t)N * H * W * 2 * COUT, w_n = (size_t)C3 * COUT * 9;
     _Float16 *din, *dw, *dout; float* db;
     CK(hipMalloc(&din, in_n * 2)); CK(hipMalloc(&dw, w_n * 2)); CK(hipMalloc(&dout, out_n * 2)); CK(hipMalloc(&db, COUT * 4));
@@ -125,8 +134,8 @@ static void timing(const char* layer, int N, int H, int W, double wino_ms) {
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
     const double flops = 2.0 * CIN * COUT * 9 * (double)N * H * W;
-    std::printf("%-13s %3d -> %3d  %3dx%-3d  split (3 x CIN as fp16 channels): %.4f ms = %6.1f TFLOP/s of fp32 work (%5.0f executed, %.2f of 2,500)   fp32 Winograd F(4x2) launch: %.3f ms   ratio %.2f\n",
-                layer, CIN, COUT, H, W, ms, flops / ms / 1e9, 3 * flops / ms / 1e9, 3 * flops / ms / 1e9 / 2500.0, wino_ms, ms / wino_ms);
+    std::printf("%-13s %3d -> %3d  %3dx%-3d  split (%d x CIN half channels): %.4f ms = %6.1f TFLOP/s of fp32 work (%5.0f executed, %.2f of 2,500)   fp32 Winograd F(4x2) launch: %.3f ms   ratio %.2f\n",
+                layer, CIN, COUT, H, W, CMUL, ms, flops / ms / 1e9, 3 * flops / ms / 1e9, 3 * flops / ms / 1e9 / 2500.0, wino_ms, ms / wino_ms);
     std::fflush(stdout);
     CK(hipFree(din)); CK(hipFree(dw)); CK(hipFree(dout)); CK(hipFree(db));
 }
