@@ -25,6 +25,7 @@ Extra objects on that line:
   configs       (N=1 only) short legs at BASELINE.json configs[3] (B=256, 256x256, fp32) and configs[4] (B=512, fp16
                 storage): images/sec, slowest launch, parity spot check
   hot_weights_leg, dist_world1_leg  (N=1 only) 5 steps on the He-gain weight set; RCCL communicator + weights broadcast at world size 1
+  split16_leg   (N=1 only) the opt-in split-operand algorithm of the 3x3 layers (conv_algo="split16") on the same batch: images/sec and error on both weight sets
   rccl, parity.max_abs_err_all_ranks  (N>1, or --force-dist) what RCCL reports for the weights communicator and the one broadcast; the worst
                 error over ALL ranks of two images of each rank's own shard against the CPU oracle (ranks > 0 run on the broadcast weights)
   rehearsal     only with --rehearse-shared-gpu: the N>1 code path with all ranks on cuda:0 over gloo (one-GPU boxes); not a scaling number
@@ -528,6 +529,28 @@ def main():
                 del mh, yh2
             except Exception as e:  # pragma: no cover
                 res["hot_weights_leg"] = {"error": str(e)[:200]}
+            # (c) the OPT-IN split-operand algorithm of the eight 3x3 layers (include/cid.h CID_ALGO_SPLIT16): same fp32 tensors, fp32 operands as hi + lo halfs,
+            # three fp16-MFMA products per multiply, fp32 accumulation.  Reported beside the headline, never as it: `value` above is plain fp32 arithmetic.
+            try:
+                from oracle import torch_oracle
+
+                legs = {}
+                for wname in ("default", "hot"):
+                    sdw = sd if wname == "default" else synth.make_state_dict("hot")
+                    ms_ = cid.load(sdw, device=dev, strict=True)
+                    ms_.conv_algo, ms_.tail_algo = "split16", "bands"
+                    el, lms, nf, ys = timed_forwards(ms_, x, 10, 3)
+                    refs = torch_oracle.forward(sdw, x_host[:4]).numpy()
+                    legs[wname] = {"images_per_sec": round(B * 10 / el, 1), "ms_per_step": round(el / 10 * 1e3, 3),
+                                   "max_abs_err_vs_cpu_oracle": float(np.abs(ys[:4].cpu().numpy() - refs).max()),
+                                   "layers_ms": [round(v / max(nf, 1), 4) for v in lms]}
+                    del ms_, ys
+                res["split16_leg"] = {"conv_algo": "split16", "tail_algo": "bands", "steps": 10, "warmup": 3, "weights": legs,
+                                      "vs_default_algorithm": round(legs["default"]["images_per_sec"] / res["value"], 4),
+                                      "arithmetic": "fp32 tensors; 3x3 layers: operands as hi + lo halfs, three v_mfma_f32_16x16x32_f16 products per multiply, fp32 accumulate "
+                                                    "(error vs float64 equal to fp32 accumulation's; parity tests at the same 1e-5) - opt-in, not the headline configuration"}
+            except Exception as e:  # pragma: no cover
+                res["split16_leg"] = {"error": str(e)[:300]}
             if not use_dist:
                 try:
                     import socket

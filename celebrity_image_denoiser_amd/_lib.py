@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("CID_LIB_PATH") or os.path.join(_HERE, "libcid.so")
 CID_OK = 0
 CID_NUM_PARAMS = 24
 CID_NUM_LAUNCHES = 12
-CID_ALGO_DIRECT, CID_ALGO_WINOGRAD64, CID_ALGO_WINOGRAD42 = 0, 2, 3
+CID_ALGO_DIRECT, CID_ALGO_WINOGRAD64, CID_ALGO_WINOGRAD42, CID_ALGO_SPLIT16 = 0, 2, 3, 4
 CID_FMT_F32_NCHW, CID_FMT_U8_NHWC = 0, 1
 CID_DTYPE_F32, CID_DTYPE_F16 = 0, 1
 CID_TAIL_FUSED, CID_TAIL_BANDS, CID_TAIL_TILES = 0, 1, 2

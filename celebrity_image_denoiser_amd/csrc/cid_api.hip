@@ -49,6 +49,11 @@ const char* kWino64KernelNames[NL] = {
     "k_wino64_conv<128, 256, false,", "k_wino64_conv<256, 256, false,", nullptr, "k_wino64_conv<256, 128, false,",
     "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
 };
+const char* kSplitKernelNames[NL] = {   // conv_algo = "split16": the eight 3x3 layers on k_conv3x3_h16<..., F32IO = true>; everything else as the direct configuration
+    nullptr, "k_conv3x3_h16<64, 64, 1, false, false, true>", "k_conv3x3_h16<64, 128, 0, false, false, true>", "k_conv3x3_h16<128, 128, 1, false, false, true>",
+    "k_conv3x3_h16<128, 256, 0, false, false, true>", "k_conv3x3_h16<256, 256, 0, false, false, true>", nullptr, "k_conv3x3_h16<256, 128, 0, false, false, true>",
+    "k_conv3x3_h16<128, 128, 0, false, false, true>", nullptr, "k_conv3x3_h16<128, 64, 0, false, false, true>", nullptr,
+};
 const char* kWino42KernelNames[NL] = {
     nullptr, "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
     "k_wino42_conv<128, 256, false,", "k_wino42_conv<256, 256, false,", nullptr, "k_wino42_conv<256, 128, false,",
@@ -72,7 +77,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, s_off[NL], total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -102,6 +107,10 @@ struct BlobLayout {
         tab42_off[0] = o; o = align_up(o + wino42_slot_table<8>(nullptr), 64);   // its LDS slot tables, TC = 8 and 4
         tab42_off[1] = o; o = align_up(o + wino42_slot_table<4>(nullptr), 64);
         hz_off = o; o = align_up(o + 3 * 2 * 64 * 8 / 2, 64);   // fp16 path, fused last layer: upconv1[2] as A fragments [2 row tiles][2 k-steps][64 lanes][8] halfs (room for three, as round 4's first form had)
+        for (int l = 0; l < NL; ++l) {   // conv_algo = "split16": hi | lo | hi half pieces of the eight 3x3 layers' weights, in the order k_conv3x3_h16<F32IO> consumes them (27 halfs per weight)
+            s_off[l] = o;
+            if (kLayers[l].kind == CONV) o = align_up(o + ((size_t)kLayers[l].cin * kLayers[l].cout * 27 + 1) / 2, 64);
+        }
         total = o;
     }
 };
@@ -221,6 +230,15 @@ size_t packed_index_h16(const LayerDef& L, int co, int ci, int kh, int kw) {
     return ((((((size_t)(nb * nchunk + ck) * 3 + kw) * 3 + kh) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
 }
 
+// conv_algo = "split16" (k_conv3x3_h16<F32IO>): [column block nb][chunk ck of 32 fp32 channels][j = 0..8][kh][channel group cg][lane = 16 kg + col][8] halfs, where sub-chunk
+// j = 0..2 is tap column kw = j of hi_w (met by hi_x), j = 3..5 kw = j - 3 of lo_w (met by hi_x), j = 6..8 kw = j - 6 of hi_w again (met by lo_x); hi_w = half(w), lo_w = half(w - hi_w)
+size_t packed_index_s16(const LayerDef& L, int co, int ci, int kh, int j) {
+    const int nb = co >> 6, cg = co & 3, c = (co >> 2) & 15;
+    const int ck = ci >> 5, kg = (ci >> 3) & 3, e = ci & 7;
+    const int nchunk = L.cin / 32;
+    return ((((((size_t)(nb * nchunk + ck) * 9 + j) * 3 + kh) * 4 + cg) * 64) + kg * 16 + c) * 8 + e;
+}
+
 struct Dims {
     int N, H, W, H1, W1, H2, W2, Hu2, Wu2, Hu1, Wu1;
 };
@@ -297,7 +315,7 @@ namespace {
 // The fused form lives in the epilogue of upconv1[0]'s kernel: the Winograd kernels on the fp32 path (not the 9-tap direct one), k_conv3x3_h16 on the
 // fp16-storage path (one 3x3 algorithm there, so always).
 bool fused_tail_active(cid_handle_t h) {
-    return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || h->algo != CID_ALGO_DIRECT);
+    return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || (h->algo != CID_ALGO_DIRECT && h->algo != CID_ALGO_SPLIT16));
 }
 
 int fail(cid_handle_t h, int code, const std::string& msg) {
@@ -493,6 +511,19 @@ template <int CIN, int COUT, int MODE>
 hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer, const float* in, int Hin, int Win, int in_ps,
                           float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
     if (algo == 0) return launch_gemm<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+    if (algo == CID_ALGO_SPLIT16) {
+        // split-operand convolution on the fp16 MFMA, fp32 tensors in and out (conv_kernels_f16.h, F32IO): one (8x32-pixel tile, 64-channel column block) per workgroup, two per CU
+        if (in_ps != CIN) return hipErrorInvalidValue;   // the kernel takes the pixel stride of its input as CIN (true of every layer of this network)
+        GemmConvArgsH a;
+        a.in = reinterpret_cast<const _Float16*>(in); a.w = reinterpret_cast<const _Float16*>(blob + kBlob.s_off[layer]); a.bias = blob + kBlob.b_off[layer];
+        a.out = reinterpret_cast<_Float16*>(out); a.pool = reinterpret_cast<_Float16*>(pool);
+        a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
+        const TileGrid g = tiles_for(N, Hc, Wc);
+        a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+        a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty); a.walk = 0;
+        hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, false, false, true>), dim3(8 * g.per_xcd * (COUT / NTILE)), dim3(THREADS), 0, s, a);
+        return hipGetLastError();
+    }
     WinoArgs a;
     a.in = in; a.u = blob + kBlob.u_off[layer]; a.bias = blob + kBlob.b_off[layer]; a.slot_tab = nullptr;
     a.out = out; a.pool = pool; a.zw = nullptr; a.zout = nullptr;
@@ -772,6 +803,14 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                 hz[(((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
         }
+        if (L.kind == CONV) {   // split-operand pieces (conv_algo = "split16")
+            _Float16* sp = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.s_off[l]);
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                const float v = data[ref_index(L, co, ci, kh, kw)];
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                sp[packed_index_s16(L, co, ci, kh, kw)] = hi; sp[packed_index_s16(L, co, ci, kh, 3 + kw)] = lo; sp[packed_index_s16(L, co, ci, kh, 6 + kw)] = hi;
+            });
+        }
         if (L.kind == CONV || L.kind == CONVT) {
             _Float16* hd = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.h_off[l]);
             for_each_weight(L, [&](int co, int ci, int kh, int kw) {
@@ -993,6 +1032,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
         if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true," : "k_conv_tail_zh<";
         return kHalfKernelNames[i];
     }
+    if (h && h->algo == CID_ALGO_SPLIT16) return kSplitKernelNames[i] ? kSplitKernelNames[i] : kKernelNames[i];
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];
     if (h && h->algo != CID_ALGO_DIRECT && kWino64KernelNames[i]) return kWino64KernelNames[i];
     return kKernelNames[i];
@@ -1000,7 +1040,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
 
 int cid_set_conv_algo(cid_handle_t h, int algo) {
     if (!h) return CID_ERR_INVALID;
-    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64 && algo != CID_ALGO_WINOGRAD42) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
+    if (algo != CID_ALGO_DIRECT && algo != CID_ALGO_WINOGRAD64 && algo != CID_ALGO_WINOGRAD42 && algo != CID_ALGO_SPLIT16) return fail(h, CID_ERR_INVALID, "cid_set_conv_algo: unknown algorithm");
     h->algo = algo;
     return CID_OK;
 }

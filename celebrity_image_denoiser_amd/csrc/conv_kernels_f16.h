@@ -280,6 +280,64 @@ __device__ __forceinline__ void h16_epilogue(const Args& a, f32x4 (&acc)[2][2][4
     }
 }
 
+// F32IO (conv_algo = "split16"): the same epilogue writing FP32 tensors — a lane's four channel groups are four consecutive channels = 16 bytes; a.out / a.pool point to float data,
+// out_ps / out_coff count floats.
+template <int COUT, int MODE, typename Args>
+__device__ __forceinline__ void h16_epilogue_f32(const Args& a, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0, int wave, int lane, int cobase) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const bool full = y0 + TILE_H <= a.Hs && x0 + TILE_W <= a.Ws;
+    const int c16 = lane & 15, kg = lane >> 4, pb = (0xa802 >> (4 * kg)) & 15;
+    // 16-byte buffer store with a scalar offset, its data registers held untouched for four more wait states: the store-data hazard of the register-soffset form
+    // (wino42_kernels.h store16, profiles/r03_store_hazard.txt; tools/store_hazard_check.py found the unguarded form of this epilogue at once)
+    auto store16 = [](f32x4 v, const __amdgpu_buffer_rsrc_t& rsrc, unsigned vo, unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rsrc, vo, soff, /*nt*/ 2);
+        asm volatile("s_nop 3" ::"v"(v) : "memory");
+    };
+    auto image_out = [&](float* base, size_t elems) {
+        const unsigned long long p = (unsigned long long)(base + (size_t)n * elems);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)(elems * 4), 0x00020000);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t ro = image_out(reinterpret_cast<float*>(a.out), (size_t)a.Hs * a.Ws * a.out_ps);
+        const unsigned lane_off = (unsigned)((pb * a.out_ps + 4 * c16) * 4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = __builtin_amdgcn_readfirstlane(y0 + 2 * wave + m);
+            const unsigned row_off = (unsigned)(((y * a.Ws + x0) * a.out_ps + a.out_coff + cobase) * 4);
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dp = 16 * pg + (r & 1) + 4 * (r >> 1);
+                    const f32x4 v = {fmaxf(acc[m][pg][0][r] + bias_v[0], 0.f), fmaxf(acc[m][pg][1][r] + bias_v[1], 0.f), fmaxf(acc[m][pg][2][r] + bias_v[2], 0.f), fmaxf(acc[m][pg][3][r] + bias_v[3], 0.f)};
+                    const unsigned vo = (full || (y < a.Hs && pb + dp < a.Ws - x0)) ? lane_off : 0x7ffffff0u;
+                    store16(v, ro, vo, row_off + (unsigned)(dp * a.out_ps * 4));
+                }
+        }
+    }
+    if (MODE == 1) {   // 2x2 max-pool, floor mode (as h16_epilogue)
+        const int Hp = a.Hc >> 1, Wp = a.Wc >> 1;
+        const int py = __builtin_amdgcn_readfirstlane((y0 >> 1) + wave);
+        const __amdgpu_buffer_rsrc_t rp = image_out(reinterpret_cast<float*>(a.pool), (size_t)Hp * Wp * COUT);
+        const unsigned prow_off = (unsigned)(((py * Wp + (x0 >> 1)) * COUT + cobase) * 4);
+        const int p0 = pb >> 1;
+        const unsigned lane_off = (unsigned)((p0 * COUT + 4 * c16) * 4);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int dp = 8 * pg + 2 * r;
+                f32x4 v;
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+                    v[cg] = fmaxf(fmaxf(fmaxf(acc[0][pg][cg][2 * r], acc[0][pg][cg][2 * r + 1]), fmaxf(acc[1][pg][cg][2 * r], acc[1][pg][cg][2 * r + 1])) + bias_v[cg], 0.f);
+                const unsigned vo = (py < Hp && p0 + dp < Wp - (x0 >> 1)) ? lane_off : 0x7ffffff0u;
+                store16(v, rp, vo, prow_off + (unsigned)(dp * COUT * 4));
+            }
+    }
+}
+
 // ZOUT epilogue of k_conv3x3_h16<128, 64> (round 4): upconv1[0] as the producer of the last layer's input.  What the fp32 path does since
 // round 2 (wino42_kernels.h, ZOUT): upconv1[2] = Conv2d(64, 3, 3, padding=1) (app.py:77) is a 1x1 contraction per tap followed by a
 // nine-tap shifted sum, and the contraction has no halo — so it runs HERE, on the wave's finished 2 rows x 32 pixels x 64 channels, and
@@ -379,8 +437,8 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
 //     accumulators it measures faster than walking on every layer (profiles/r04_ab_f16_walk_vs_not.txt), and as a compile-time fact it removes the
 //     next-item decode, the prefetch under the last sub-step and the item boundary from the code.  WALK = true (cid_debug_half_workgroups_per_cu > 0)
 //     stays a tested option with the same bits.
-template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false>
-__global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH a) {
+template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false, bool F32IO = false>
+__global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const GemmConvArgsH a) {
 #ifndef CID_EXPERIMENTS
     static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
@@ -389,8 +447,10 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
     constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see above
     static_assert(PLANE % 16 == 4, "the fragment row permutation below assumes plane stride = 4 mod 16");
-    constexpr int NSLOT = LPIX * 4, NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6
-    constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * 3;
+    // F32IO (conv_algo = "split16" of the fp32 path): CIN counts FP32 channels; a chunk = 32 of them = 128 bytes per pixel in 8 pieces of 16 bytes, split into a hi and a lo set of planes
+    // while staging; nine sub-steps per chunk (hi_x . hi_w, hi_x . lo_w, lo_x . hi_w for each tap column), the host packs the weight sub-chunks in that order
+    constexpr int NSLOT = LPIX * (F32IO ? 8 : 4), NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6 (11)
+    constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * (F32IO ? 9 : 3);
     constexpr int NB = COUT / NTILE;
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     // (r4) ... and the k-group planes lie at 0, PLANE, 2 PLANE + 2, 3 PLANE + 2: the pairs (0,1) and (2,3) that share a ds_read_b128 service group stay
@@ -400,7 +460,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     constexpr int PLANE_GAP = 2;
     constexpr int HALO_SLOTS = 4 * PLANE + PLANE_GAP;
     // LDS: [B buffer 0][B buffer 1][halo planes]: 46.0 KiB -> three workgroups per CU (the epilogue stores from registers, round 4)
-    constexpr int LDS_SLOTS = 2 * BSUB + HALO_SLOTS;
+    constexpr int LDS_SLOTS = 2 * BSUB + (F32IO ? 2 : 1) * HALO_SLOTS;   // F32IO: hi planes, then lo planes (66.6 KiB: two workgroups per CU)
     constexpr int HB = 2 * BSUB;                                          // first halo slot
     static_assert(NSUB % 2 == 0, "the last sub-step must read B buffer 1");
     __shared__ f32x4 lds[LDS_SLOTS];
@@ -425,11 +485,11 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
     }
     // the input tensor's pixel stride is the layer's CIN on every layer of this network (cat1 / cat2 hold exactly the channels their
     // consumer reads): a compile-time constant instead of a kernel argument held in an SGPR (the host asserts it)
-    const size_t img_elems = (size_t)a.Hin * a.Win * CIN;
+    const size_t img_elems = (size_t)a.Hin * a.Win * CIN * (F32IO ? 2 : 1);   // in halfs (a.in is a half pointer)
     auto image_rsrc = [&](int img) {   // base through readfirstlane: the descriptor must live in SGPRs
         const unsigned long long p = (unsigned long long)(a.in + (size_t)img * img_elems);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * CIN * 2, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, a.Hin * a.Win * CIN * (F32IO ? 4 : 2), 0x00020000);
     };
     // halo pieces: piece s = it*256 + tid = (pixel s >> 2, k-group s & 3) -> LDS slot HB + (tid & 3) * PLANE + (tid >> 2) + 64 it
     bool abl_on = false;   // H16_ABLATE: a workgroup's first item runs in full (so LDS holds real data), the ablation applies from its second
@@ -438,29 +498,41 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it) {
             const int sidx = it * THREADS + lane_id;
-            const int p = sidx >> 2, q = sidx & 3;
+            const int p = F32IO ? sidx >> 3 : sidx >> 2, q = F32IO ? sidx & 7 : sidx & 3;
             const int hy = p / LW, hx = p - hy * LW;
             const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
             const bool ok = p < LPIX && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
-            goff[it] = ok ? (unsigned)(((gy * a.Win + gx) * CIN + q * 8) * 2) : 0x7ffffff0u;
+            goff[it] = ok ? (F32IO ? (unsigned)(((gy * a.Win + gx) * CIN + q * 4) * 4) : (unsigned)(((gy * a.Win + gx) * CIN + q * 8) * 2)) : 0x7ffffff0u;
         }
     };
-    const int hbase = HB + (tid & 3) * PLANE + ((tid & 2) ? PLANE_GAP : 0) + (tid >> 2);
-    const bool halo_last = (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
+    // F32IO: piece (pixel tid >> 3 + 32 it, q = tid & 7) = fp32 channels 4q..4q+3 of the chunk = half h = q & 1 of the quad of k-group q >> 1
+    const int hbase = F32IO ? HB + ((tid & 7) >> 1) * PLANE + ((tid & 4) ? PLANE_GAP : 0) + (tid >> 3)
+                            : HB + (tid & 3) * PLANE + ((tid & 2) ? PLANE_GAP : 0) + (tid >> 2);
+    const bool halo_last = F32IO ? (NLOAD - 1) * 32 + (tid >> 3) < LPIX : (NLOAD - 1) * 64 + (tid >> 2) < LPIX;          // does this thread's last piece exist (pixels 320..339 of 340)
     f32x4 pre[NLOAD];
     auto request_halo = [&](const __amdgpu_buffer_rsrc_t& rsrc, int ck, int zs) {
         if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * 64, 0));
+        for (int it = 0; it < NLOAD; ++it) pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], zs + ck * (F32IO ? 128 : 64), 0));
     };
     auto halo_to_lds = [&]() {
         if ((H16_ABLATE & 2) && abl_on) return;
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it)
-            if (it + 1 < NLOAD || halo_last) lds[hbase + it * 64] = pre[it];
+        for (int it = 0; it < NLOAD; ++it) {
+            if (F32IO) {   // four fp32 channels -> their hi halfs (8 bytes into the hi planes) and the halfs of what hi leaves (the lo planes)
+                if (it + 1 < NLOAD || halo_last) {
+                    const f32x4 v = pre[it];
+                    const f16x4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    const f16x4 lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]), (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
+                    f16x4* dst = reinterpret_cast<f16x4*>(lds + hbase + it * 32) + (tid & 1);
+                    dst[0] = hi;
+                    dst[2 * HALO_SLOTS] = lo;
+                }
+            } else if (it + 1 < NLOAD || halo_last) lds[hbase + it * 64] = pre[it];
+        }
     };
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2 * (F32IO ? 3 : 1), 0x00020000);
     const unsigned vlane = lane * 16;
     auto dma_b = [&](int wb, int g) {   // wb = byte offset of the item's column block in the packed weights
         if ((H16_ABLATE & 1) && abl_on) return;
@@ -587,8 +659,9 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         __syncthreads();
     };
     auto seam_keep_halo = [&]() {   // the same with the NLOAD halo loads issued behind the B DMA still in flight
-        static_assert(NLOAD == 6, "vmcnt immediate below");
+        static_assert(NLOAD == (F32IO ? 11 : 6), "vmcnt immediate below");
         if (H16_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (F32IO) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
     };
@@ -609,6 +682,19 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
 #ifdef H16_TRACE
         tr_lap(tr_bnd);     // prologue of the first item / boundary of the later ones
 #endif
+        if constexpr (F32IO) {   // nine sub-steps per 32-channel chunk — tap columns 0..2 on the hi planes against hi_w, again against lo_w, then on the
+            // lo planes against hi_w; the packed weights hold the sub-chunks in this order, so sub-step q reads sub-chunk q.  The next chunk is requested in sub-step 7.
+            static_assert(!WALK && !ZOUT, "prototype: one item per workgroup, plain epilogue");
+            substep(T{}, F{}, 0, 0); seam();
+            for (int q = 1; q < NSUB - 1; ++q) {
+                const int ck = q / 9, j = q - 9 * ck;
+                const int dx = (j >= 6 ? j - 6 + HALO_SLOTS : j >= 3 ? j - 3 : j);          // + HALO_SLOTS: the lo planes
+                const int req = (j == 7 && ck + 1 < NCHUNK) ? ck + 1 : -1;
+                substep(F{}, F{}, q, dx, req);
+                if (j == 8) chunk_seam(); else if (req >= 0) seam_keep_halo(); else seam();
+            }
+            substep(F{}, T{}, NSUB - 1, 2 + HALO_SLOTS);
+        } else {
 #ifdef H16_SPLIT_IN
         {   // experiment (csrc/tools/split_proto, -DCID_EXPERIMENTS): split-operand fp32 convolution.  A pixel holds [hi | lo] halfs of C = CIN / 2 fp32 channels, the packed
             // weights [hi_w | lo_w] as 2 C input channels.  Halo chunk ck < NCH (hi_x) runs SIX sub-steps — its three tap columns against hi_w, then against lo_w, from the same
@@ -645,6 +731,7 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
         substep(F{}, F{}, NSUB - 2, 1); seam();
         substep(F{}, T{}, NSUB - 1, 2);
 #endif
+        }
 
 #ifdef H16_TRACE
         asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
@@ -657,6 +744,8 @@ __global__ void __launch_bounds__(THREADS, 3) k_conv3x3_h16(const GemmConvArgsH 
                 __syncthreads();   // every wave has read its last fragments: B buffer 1 and the halo planes become the staging area (32 KiB)
                 static_assert(4 * 512 <= LDS_SLOTS - BSUB, "z staging must fit behind B buffer 0 (the next item's first B sub-chunk lands there)");
                 h16_zout_epilogue(a, lds + BSUB, acc, bias_v, n, y0, x0, wave, lane_e);
+            } else if constexpr (F32IO) {
+                h16_epilogue_f32<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
             } else {
                 h16_epilogue<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
             }

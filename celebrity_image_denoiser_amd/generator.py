@@ -370,16 +370,19 @@ class DenoiseGenerator(nn.Module):
     @property
     def conv_algo(self) -> str:
         """Algorithm of the eight 3x3 GEMM layers: "winograd42" (default; Winograd F(4x2,3x3) on MFMA, 3 multiplies per
-        output pixel and channel pair), "winograd64" (Winograd F(2x2,3x3), 4 multiplies) or "direct" (9-tap implicit GEMM, 9)."""
+        output pixel and channel pair), "winograd64" (Winograd F(2x2,3x3), 4 multiplies), "direct" (9-tap implicit GEMM, 9) — all three on the
+        exact-fp32 MFMA — or, opt-in, "split16": the direct form with every fp32 operand taken as two halfs (hi + lo) and every product as
+        three fp16-MFMA products with fp32 accumulation (include/cid.h, CID_ALGO_SPLIT16: error equal to fp32 accumulation's, inside the
+        same 1e-5 contract, but not plain fp32 arithmetic)."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
-        return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD42: "winograd42"}.get(a.value, "direct")
+        return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD42: "winograd42", _lib.CID_ALGO_SPLIT16: "split16"}.get(a.value, "direct")
 
     @conv_algo.setter
     def conv_algo(self, name: str) -> None:
-        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd64": _lib.CID_ALGO_WINOGRAD64, "winograd42": _lib.CID_ALGO_WINOGRAD42}.get(name)
+        algo = {"direct": _lib.CID_ALGO_DIRECT, "winograd64": _lib.CID_ALGO_WINOGRAD64, "winograd42": _lib.CID_ALGO_WINOGRAD42, "split16": _lib.CID_ALGO_SPLIT16}.get(name)
         if algo is None:
-            raise ValueError("conv_algo must be 'direct', 'winograd64' or 'winograd42'")
+            raise ValueError("conv_algo must be 'direct', 'winograd64', 'winograd42' or 'split16'")
         _lib.check(self._cid, _lib.lib().cid_set_conv_algo(self._cid, algo))
 
     @property

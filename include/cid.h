@@ -179,10 +179,17 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  *   CID_ALGO_WINOGRAD64 Winograd F(2x2,3x3): 4 multiplies per pixel (round 1's default)
  *   CID_ALGO_WINOGRAD42 Winograd F(4x2,3x3), tiles 4 wide x 2 high, interpolation points 0, +-3/4, +-3/2, inf: 3 multiplies
  *                       per pixel: the default
+ *   CID_ALGO_SPLIT16    (round 4, OPT-IN, not exact-fp32 MFMA) split-operand convolution on the fp16 MFMA: fp32 tensors in and out; every fp32 operand is
+ *                       taken as hi + lo with hi = half(x), lo = half(x - hi) (22 bits of mantissa), every product as hi*hi + hi*lo + lo*hi on
+ *                       v_mfma_f32_16x16x32_f16 with fp32 accumulators (lo*lo, 2^-22 relative, dropped).  9 multiplies per pixel (direct form), each on three
+ *                       half products.  Its error against float64 equals that of fp32 accumulation (1.5e-6 / 2.3e-6 on He-gain weights where ATen fp32 has
+ *                       1.6e-6 / 2.3e-6; the Winograd default: 4e-6) and it passes every 1e-5 parity test of the suite, but its arithmetic type is
+ *                       "fp32 operands as two halfs, fp16 MFMA, fp32 accumulate": the default and the headline benchmark stay on CID_ALGO_WINOGRAD42.
+ *                       The last layer runs as CID_TAIL_BANDS / CID_TAIL_TILES under this algorithm (no fused contraction).
  * (value 1 was round 1's first Winograd kernel, removed: same bits as WINOGRAD64, slower.)
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */
-enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2, CID_ALGO_WINOGRAD42 = 3 };
+enum { CID_ALGO_DIRECT = 0, CID_ALGO_WINOGRAD64 = 2, CID_ALGO_WINOGRAD42 = 3, CID_ALGO_SPLIT16 = 4 };
 
 /*
  * Storage type of activations and weights between the first and the last kernel (BASELINE configs[4]):

@@ -27,11 +27,17 @@ def _need_gpu():
         pytest.fail("GPU tests need a real MI355X (torch.cuda.is_available() is False)")
 
 
-@pytest.fixture(scope="module", params=["winograd42", "winograd64", "direct"])
+def _default_tail(algo):
+    """The last-layer form each 3x3 algorithm is tested with by default: the fused contraction needs a Winograd kernel in front of it."""
+    return {"direct": "tiles", "split16": "bands"}.get(algo, "fused")
+
+
+@pytest.fixture(scope="module", params=["winograd42", "winograd64", "direct", "split16"])
 def models(request, weight_sets):
-    """All three algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(4x2,3x3) (the default),
-    Winograd F(2x2,3x3) and the 9-tap implicit GEMM; and with them both decompositions of the last layer: fused into
-    upconv1[0]'s epilogue (default) and the tiled kernel."""
+    """All four algorithms of the 3x3 GEMM layers go through every parity test: Winograd F(4x2,3x3) (the default),
+    Winograd F(2x2,3x3), the 9-tap implicit GEMM and (round 4, opt-in) the split-operand form on the fp16 MFMA — same tensors,
+    same 1e-5 tolerance; and with them the decompositions of the last layer: fused into upconv1[0]'s epilogue (default),
+    the row-band kernel and the tiled kernel."""
     _need_gpu()
     import celebrity_image_denoiser_amd as cid
 
@@ -39,8 +45,8 @@ def models(request, weight_sets):
     for k, v in weight_sets.items():
         m = cid.load(v, device="cuda:0", strict=True)
         m.conv_algo = request.param
-        m.tail_algo = "tiles" if request.param == "direct" else "fused"
-        assert m.conv_algo == request.param and m.tail_algo == ("tiles" if request.param == "direct" else "fused")
+        m.tail_algo = _default_tail(request.param)
+        assert m.conv_algo == request.param and m.tail_algo == _default_tail(request.param)
         out[k] = m
     return out
 
@@ -435,7 +441,7 @@ def test_padded_forward_equals_pad_in_memory_bit_for_bit(models):
     m = models["hot"]
     x, _, noisy = synth.make_batch(3, 37, 50, first_index=7100)
     xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
-    tails = ("tiles",) if m.conv_algo == "direct" else ("fused", "bands", "tiles")
+    tails = ("tiles",) if m.conv_algo == "direct" else ("bands", "tiles") if m.conv_algo == "split16" else ("fused", "bands", "tiles")
     for pads in ((1, 1, 2, 1), (0, 3, 1, 0), (5, 2, 5, 5), (0, 0, 0, 0)):   # (left, top, right, bottom): 40x53, 40x51, 44x60 (37+7, 50+10), 37x50
         left, top, right, bottom = pads
         hp, wp = 37 + top + bottom, 50 + left + right
@@ -459,7 +465,7 @@ def test_padded_forward_equals_pad_in_memory_bit_for_bit(models):
                     assert torch.equal(gotf, wantf), (pads, dtype, tail)
                     assert torch.equal(m.forward_padded(xd, pads, out_u8=True), m.forward_fmt(xp, out_u8=True)[:, top:top + 37, left:left + 50, :])
                 finally:
-                    m.compute_dtype, m.tail_algo = "f32", ("tiles" if m.conv_algo == "direct" else "fused")
+                    m.compute_dtype, m.tail_algo = "f32", _default_tail(m.conv_algo)
 
 
 def test_walking_workgroups_equal_one_item_per_workgroup(weight_sets):
