@@ -435,7 +435,8 @@ def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
     """[(layer name, kernel symbol, algorithmic flops, algorithmic bytes, executed flops)] of one forward, per LAUNCH under
     `model`'s configuration (direct kernels, unfused, if no model is given).  Algorithmic = the direct-convolution count of
     the reference layer(s) the launch computes; executed = what its MFMAs issue: the Winograd kernels run 24/72 (F(4x2,3x3)) or 16/36 (F(2x2,3x3)) of
-    their 3x3 layer's multiplies (a fused-in contraction of the next layer is executed as it stands)."""
+    their 3x3 layer's multiplies (a fused-in contraction of the next layer is executed as it stands); the split-operand kernels (conv_algo "split16")
+    issue THREE fp16-MFMA products per multiply."""
     L = _lib.lib()
     rows = []
     handle = model._cid if model is not None else None
@@ -445,6 +446,7 @@ def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
         _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f0), ctypes.byref(b0)))
         kern = L.cid_launch_kernel(handle, i).decode()
         own = min(f.value, f0.value)                       # the launch's own layer (0 for a launch that only sums)
-        executed = own * (24.0 / 72.0 if "wino42" in kern else 16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
+        split = kern.startswith("k_conv3x3_h16") and kern.rstrip().endswith("true>")      # conv_algo "split16": three fp16-MFMA products per multiply
+        executed = own * (3.0 if split else 24.0 / 72.0 if "wino42" in kern else 16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
         rows.append((L.cid_launch_name(i).decode(), kern, f.value, b.value, executed))
     return rows
