@@ -992,6 +992,40 @@ def test_white_noise_inputs_stay_within_the_fp32_contract(models, weight_sets, w
     assert err_cb <= TOL, (models[wset].conv_algo, wset, err_cb)
 
 
+def test_split16_wide_images_batch_independence_and_error_budget(weight_sets):
+    """conv_algo="split16" (opt-in; include/cid.h CID_ALGO_SPLIT16) beyond what the per-algorithm fixture sees: (a) 256 x 256 images (the row-band last layer
+    does not take them: the handle falls back to the tiled one) and a ragged 250 x 300 against the ATen oracle at the fp32 path's 1e-5, on the He-gain weights;
+    (b) batch independence, bit for bit: images of a 40-image batch (grid of 10,240 workgroups per layer) equal the same images run alone; (c) on 8 He-gain images
+    the split form and the exact-fp32 direct kernel stand at the same distance from the ATen oracle (measured 5.8e-6 and 5-7e-6: fp32-grade sums in different orders), both inside 1e-5."""
+    _need_gpu()
+    import celebrity_image_denoiser_amd as cid
+    from oracle import torch_oracle
+
+    sd = weight_sets["hot"]
+    m = cid.load(sd, device="cuda:0", strict=True)
+    m.conv_algo, m.tail_algo = "split16", "bands"
+    for shape in ((2, 256, 256), (1, 250, 300)):
+        x, _, _ = synth.make_batch(shape[0], shape[1], shape[2], first_index=4242)
+        y = _run(m, x)
+        ref = torch_oracle.forward(sd, x).numpy()
+        assert y.shape == ref.shape and float(np.abs(y - ref).max()) <= TOL, shape
+    x, _, _ = synth.make_batch(40, 128, 128, first_index=5100)
+    xd = torch.from_numpy(x).to("cuda:0")
+    yb = m(xd).clone()
+    for i in (0, 19, 39):
+        assert torch.equal(m(xd[i:i + 1].contiguous()), yb[i:i + 1]), i
+    ref8 = torch_oracle.forward(sd, x[:8]).numpy()
+    err = float(np.abs(yb[:8].cpu().numpy() - ref8).max())
+    md = cid.load(sd, device="cuda:0", strict=True)
+    md.conv_algo, md.tail_algo = "direct", "bands"
+    err_direct = float(np.abs(_run(md, x[:8]) - ref8).max())
+    assert err <= TOL and err_direct <= TOL and err <= 2.0 * err_direct, (err, err_direct)
+    from celebrity_image_denoiser_amd import _lib
+
+    names = [_lib.lib().cid_launch_kernel(m._cid, i).decode() for i in range(12)]
+    assert sum(n.startswith("k_conv3x3_h16<") and n.endswith("true>") for n in names) == 8 and names[0].startswith("k_conv_head") and names[9].startswith("k_convt_s32")
+
+
 def test_config3_full_size_256x256_batch_256(weight_sets):
     """BASELINE configs[3] at its REAL size — B = 256 images of 256 x 256 (31.7 GB arena) — which the suite so far
     saw only at N = 1.  Size-independent properties, on the default algorithm: (a) batch independence: three images of the
