@@ -554,7 +554,7 @@ def main():
                 res["split16_leg"] = {"conv_algo": "split16", "tail_algo": "bands", "steps": 10, "warmup": 3, "weights": legs,
                                       "vs_default_algorithm": round(legs["default"]["images_per_sec"] / res["value"], 4),
                                       "arithmetic": "fp32 tensors; 3x3 layers: operands as hi + lo halfs, three v_mfma_f32_16x16x32_f16 products per multiply, fp32 accumulate "
-                                                    "(error vs float64 equal to fp32 accumulation's; parity tests at the same 1e-5) - opt-in, not the headline configuration"}
+                                                    "(error vs float64 1.2x the exact-fp32 direct kernel's, 2-3x ATen fp32's: profiles/r04_accuracy_study.txt; parity tests at the same 1e-5) - opt-in, not the headline configuration"}
             except Exception as e:  # pragma: no cover
                 res["split16_leg"] = {"error": str(e)[:300]}
             if not use_dist:

@@ -372,8 +372,8 @@ class DenoiseGenerator(nn.Module):
         """Algorithm of the eight 3x3 GEMM layers: "winograd42" (default; Winograd F(4x2,3x3) on MFMA, 3 multiplies per
         output pixel and channel pair), "winograd64" (Winograd F(2x2,3x3), 4 multiplies), "direct" (9-tap implicit GEMM, 9) — all three on the
         exact-fp32 MFMA — or, opt-in, "split16": the direct form with every fp32 operand taken as two halfs (hi + lo) and every product as
-        three fp16-MFMA products with fp32 accumulation (include/cid.h, CID_ALGO_SPLIT16: error equal to fp32 accumulation's, inside the
-        same 1e-5 contract, but not plain fp32 arithmetic)."""
+        three fp16-MFMA products with fp32 accumulation (include/cid.h, CID_ALGO_SPLIT16: the least accurate of the four — 1.2x the direct fp32 kernel's error,
+        2-3x ATen fp32's — inside the same 1e-5 contract, and not plain fp32 arithmetic)."""
         a = ctypes.c_int()
         _lib.check(self._cid, _lib.lib().cid_get_conv_algo(self._cid, ctypes.byref(a)))
         return {_lib.CID_ALGO_WINOGRAD64: "winograd64", _lib.CID_ALGO_WINOGRAD42: "winograd42", _lib.CID_ALGO_SPLIT16: "split16"}.get(a.value, "direct")
