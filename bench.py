@@ -340,8 +340,6 @@ def main():
     # rank 0 owns the checkpoint; everyone else starts from its own random init and receives the blob
     model = cid.load(sd if rank == 0 else None, device=dev, strict=True)
     model.conv_algo = args.algo
-    if args.algo == "split16":
-        model.tail_algo = "bands" if S <= 128 else "tiles"
     model.compute_dtype = args.dtype
     bcast = None
     if use_dist:
@@ -544,14 +542,14 @@ def main():
                 for wname in ("default", "hot"):
                     sdw = sd if wname == "default" else synth.make_state_dict("hot")
                     ms_ = cid.load(sdw, device=dev, strict=True)
-                    ms_.conv_algo, ms_.tail_algo = "split16", "bands"
+                    ms_.conv_algo = "split16"
                     el, lms, nf, ys = timed_forwards(ms_, x, 10, 3)
                     refs = torch_oracle.forward(sdw, x_host[:4]).numpy()
                     legs[wname] = {"images_per_sec": round(B * 10 / el, 1), "ms_per_step": round(el / 10 * 1e3, 3),
                                    "max_abs_err_vs_cpu_oracle": float(np.abs(ys[:4].cpu().numpy() - refs).max()),
                                    "layers_ms": [round(v / max(nf, 1), 4) for v in lms]}
                     del ms_, ys
-                res["split16_leg"] = {"conv_algo": "split16", "tail_algo": "bands", "steps": 10, "warmup": 3, "weights": legs,
+                res["split16_leg"] = {"conv_algo": "split16", "tail_algo": "fused", "steps": 10, "warmup": 3, "weights": legs,
                                       "vs_default_algorithm": round(legs["default"]["images_per_sec"] / res["value"], 4),
                                       "arithmetic": "fp32 tensors; 3x3 layers: operands as hi + lo halfs, three v_mfma_f32_16x16x32_f16 products per multiply, fp32 accumulate "
                                                     "(error vs float64 1.2x the exact-fp32 direct kernel's, 2-3x ATen fp32's: profiles/r04_accuracy_study.txt; parity tests at the same 1e-5) - opt-in, not the headline configuration"}

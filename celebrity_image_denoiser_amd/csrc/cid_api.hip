@@ -77,7 +77,7 @@ size_t packed_weight_count(const LayerDef& L) {
 // The reference-layout copy makes the blob self-describing (state_dict() after a broadcast is exact: U is
 // not invertible bit-for-bit).
 struct BlobLayout {
-    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, s_off[NL], total;
+    size_t w_off[NL], b_off[NL], u_off[NL], u42_off[NL], h_off[NL], raw_w_off[NL], raw_b_off[NL], tab_off[2], tab42_off[2], hz_off, s_off[NL], hzs_off, total;
     BlobLayout() {
         size_t o = 0;
         for (int l = 0; l < NL; ++l) {
@@ -111,6 +111,7 @@ struct BlobLayout {
             s_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + ((size_t)kLayers[l].cin * kLayers[l].cout * 27 + 1) / 2, 64);
         }
+        hzs_off = o; o = align_up(o + 2 * 2 * 2 * 64 * 8 / 2, 64);   // split16, fused last layer: upconv1[2] as A fragments [hi | lo][2 row tiles][2 k-steps][64 lanes][8] halfs
         total = o;
     }
 };
@@ -315,7 +316,7 @@ namespace {
 // The fused form lives in the epilogue of upconv1[0]'s kernel: the Winograd kernels on the fp32 path (not the 9-tap direct one), k_conv3x3_h16 on the
 // fp16-storage path (one 3x3 algorithm there, so always).
 bool fused_tail_active(cid_handle_t h) {
-    return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || (h->algo != CID_ALGO_DIRECT && h->algo != CID_ALGO_SPLIT16));
+    return h->tail_algo == CID_TAIL_FUSED && (h->dtype == CID_DTYPE_F16 || h->algo != CID_ALGO_DIRECT);
 }
 
 int fail(cid_handle_t h, int code, const std::string& msg) {
@@ -415,6 +416,17 @@ hipError_t launch_upconv1_0_z(int algo, hipStream_t s, const float* blob, const 
     a.out_ps = 64; a.out_coff = 0;
     a.tiles_x = a.tiles_y = a.tiles_total = a.tiles_per_xcd = 0;
     a.rcp_x = a.rcp_xy = 0; a.walk = 0;
+    if (algo == CID_ALGO_SPLIT16) {   // k_conv3x3_h16<128, 64, 0, ZOUT, ., F32IO>: `out` = the 27 fp32 z planes, `pool` = upconv1[2]'s hi | lo fragments
+        GemmConvArgsH g;
+        g.in = reinterpret_cast<const _Float16*>(in); g.w = reinterpret_cast<const _Float16*>(blob + kBlob.s_off[10]); g.bias = blob + kBlob.b_off[10];
+        g.out = reinterpret_cast<_Float16*>(zout); g.pool = const_cast<_Float16*>(reinterpret_cast<const _Float16*>(blob + kBlob.hzs_off));
+        g.N = N; g.Hin = Hc; g.Win = Wc; g.in_ps = 128; g.Hc = Hc; g.Wc = Wc; g.Hs = Hc; g.Ws = Wc; g.out_ps = 64; g.out_coff = 0;
+        const TileGrid tg = tiles_for(N, Hc, Wc);
+        g.tiles_x = tg.tx; g.tiles_y = tg.ty; g.tiles_total = tg.total; g.tiles_per_xcd = tg.per_xcd;
+        g.rcp_x = tile_rcp(tg.tx); g.rcp_xy = tile_rcp(tg.tx * tg.ty); g.walk = 0;
+        hipLaunchKernelGGL((k_conv3x3_h16<128, 64, 0, true, false, true>), dim3(8 * tg.per_xcd), dim3(THREADS), 0, s, g);
+        return hipGetLastError();
+    }
     if (algo == CID_ALGO_WINOGRAD42) {
         a.u = blob + kBlob.u42_off[10];
         if (Wc > 16) return launch_wino42_z_tc<8>(s, a, blob, 0);
@@ -802,6 +814,16 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                 const int row = 3 * (kh * 3 + kw) + co, t = row >> 4, ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
                 hz[(((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e] = (_Float16)data[ref_index(L, co, ci, kh, kw)];
             });
+            // the same fragments as hi | lo pieces for the split-operand form (h16_zout_epilogue_f32)
+            _Float16* hzs = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.hzs_off);
+            std::memset(hzs, 0, 2 * 2 * 2 * 64 * 8 * sizeof(_Float16));
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                const int row = 3 * (kh * 3 + kw) + co, t = row >> 4, ks = ci >> 5, kga = (ci >> 3) & 3, e = ci & 7;
+                const float v = data[ref_index(L, co, ci, kh, kw)];
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                const size_t at = (((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e;
+                hzs[at] = hi; hzs[4 * 64 * 8 + at] = lo;
+            });
         }
         if (L.kind == CONV) {   // split-operand pieces (conv_algo = "split16")
             _Float16* sp = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.s_off[l]);
@@ -1032,7 +1054,10 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
         if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true," : "k_conv_tail_zh<";
         return kHalfKernelNames[i];
     }
-    if (h && h->algo == CID_ALGO_SPLIT16) return kSplitKernelNames[i] ? kSplitKernelNames[i] : kKernelNames[i];
+    if (h && h->algo == CID_ALGO_SPLIT16) {
+        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true, false, true>" : "k_conv_tail_z<";
+        return kSplitKernelNames[i] ? kSplitKernelNames[i] : kKernelNames[i];
+    }
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];
     if (h && h->algo != CID_ALGO_DIRECT && kWino64KernelNames[i]) return kWino64KernelNames[i];
     return kKernelNames[i];

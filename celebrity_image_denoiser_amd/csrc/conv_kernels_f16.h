@@ -401,6 +401,74 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
         }
 }
 
+// ZOUT epilogue of k_conv3x3_h16<128, 64, 0, ZOUT, ., F32IO> (conv_algo = "split16"): upconv1[2]'s 64 -> 27 contraction per tap (as h16_zout_epilogue above) in the
+// split-operand arithmetic of the layer itself.  The wave's finished 2 rows x 32 pixels x 64 channels (bias + ReLU, fp32) are split into hi / lo halfs and staged in a
+// wave-private LDS area (hi: [row][pixel][8 slots of 8 channels], slot XOR (pixel & 7); lo: the same 8 KiB further), the weights' hi / lo pieces come as A fragments
+// (row 3 tap + co, two row tiles, two k-steps; cid_api.hip hzs_off), and z^T = hi_w.hi_x + lo_w.hi_x + hi_w.lo_x accumulates in fp32: 48 MFMAs per wave.
+// z leaves as FP32 into the 27 planes k_conv_tail_z reads, z[n][3 tap + co][y][x] (a lane holds four consecutive planes of one pixel: four 4-byte stores, 16 lanes = 64 bytes of a plane).
+template <typename Args>
+__device__ __forceinline__ void h16_zout_epilogue_f32(const Args& a, f32x4* stage, f32x4 (&acc)[2][2][4], const f32x4& bias_v, int n, int y0, int x0, int wave, int lane) {
+    const int c16 = lane & 15, kg = lane >> 4;
+    unsigned char* const stg = reinterpret_cast<unsigned char*>(stage + wave * 1024);     // hi: 2 rows x 32 pixels x 128 B, then lo
+    const int pb = (0xa802 >> (4 * kg)) & 15;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int P = 16 * pg + pb + (r & 1) + 4 * (r >> 1);
+                const float v0 = fmaxf(acc[m][pg][0][r] + bias_v[0], 0.f), v1 = fmaxf(acc[m][pg][1][r] + bias_v[1], 0.f);
+                const float v2 = fmaxf(acc[m][pg][2][r] + bias_v[2], 0.f), v3 = fmaxf(acc[m][pg][3][r] + bias_v[3], 0.f);
+                const f16x4 hi = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                const f16x4 lo = {(_Float16)(v0 - (float)hi[0]), (_Float16)(v1 - (float)hi[1]), (_Float16)(v2 - (float)hi[2]), (_Float16)(v3 - (float)hi[3])};
+                unsigned char* const d = stg + ((m * 32 + P) * 8 + ((c16 >> 1) ^ (P & 7))) * 16 + (c16 & 1) * 8;
+                *reinterpret_cast<f16x4*>(d) = hi;
+                *reinterpret_cast<f16x4*>(d + 8192) = lo;
+            }
+    f16x8 wzh[2][2], wzl[2][2];                       // requested only now, with the accumulators dead
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            wzh[t][ks] = reinterpret_cast<const f16x8*>(a.pool)[(t * 2 + ks) * 64 + lane];
+            wzl[t][ks] = reinterpret_cast<const f16x8*>(a.pool)[(4 + t * 2 + ks) * 64 + lane];
+        }
+    wave_lds_fence();
+    const size_t plane = (size_t)a.Hs * a.Ws;
+    float* const zout = reinterpret_cast<float*>(a.out) + (size_t)n * 27 * plane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+            const int P = 16 * pg + c16;
+            f16x8 xh[2], xl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* s_ = stg + ((m * 32 + P) * 8 + ((4 * ks + kg) ^ (P & 7))) * 16;
+                xh[ks] = *reinterpret_cast<const f16x8*>(s_);
+                xl[ks] = *reinterpret_cast<const f16x8*>(s_ + 8192);
+            }
+            const int y = y0 + 2 * wave + m, x = x0 + P;
+            const bool inside = y < a.Hs && x < a.Ws;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzh[t][0], xh[0], zero, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzh[t][1], xh[1], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzl[t][0], xh[0], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzl[t][1], xh[1], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzh[t][0], xl[0], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(wzh[t][1], xl[1], z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + 4 * kg + r;                                   // plane 3 tap + co
+                    if (inside && row < 27) zout[(size_t)row * plane + (size_t)y * a.Ws + x] = z[r];
+                }
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 layers of the fp16-storage path, third form: v_mfma_f32_16x16x32_f16.
 //
@@ -684,7 +752,7 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
 #endif
         if constexpr (F32IO) {   // nine sub-steps per 32-channel chunk — tap columns 0..2 on the hi planes against hi_w, again against lo_w, then on the
             // lo planes against hi_w; the packed weights hold the sub-chunks in this order, so sub-step q reads sub-chunk q.  The next chunk is requested in sub-step 7.
-            static_assert(!WALK && !ZOUT, "prototype: one item per workgroup, plain epilogue");
+            static_assert(!WALK, "one item per workgroup");
             substep(T{}, F{}, 0, 0); seam();
             for (int q = 1; q < NSUB - 1; ++q) {
                 const int ck = q / 9, j = q - 9 * ck;
@@ -740,7 +808,11 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
         {   // no barrier: the epilogue touches no LDS (round 4), so a wave stores while its siblings finish their MFMAs
             int lane_e;    // opaque copy of the lane id: keeps the epilogue's address arithmetic out of the item loop's registers
             asm volatile("v_mov_b32 %0, %1" : "=v"(lane_e) : "v"(tid & 63));
-            if constexpr (ZOUT) {
+            if constexpr (ZOUT && F32IO) {
+                __syncthreads();   // every wave has read its last fragments: the whole LDS becomes the staging area (4 x 16 KiB)
+                static_assert(4 * 1024 <= LDS_SLOTS, "hi and lo staging of four waves");
+                h16_zout_epilogue_f32(a, lds, acc, bias_v, n, y0, x0, wave, lane_e);
+            } else if constexpr (ZOUT) {
                 __syncthreads();   // every wave has read its last fragments: B buffer 1 and the halo planes become the staging area (32 KiB)
                 static_assert(4 * 512 <= LDS_SLOTS - BSUB, "z staging must fit behind B buffer 0 (the next item's first B sub-chunk lands there)");
                 h16_zout_epilogue(a, lds + BSUB, acc, bias_v, n, y0, x0, wave, lane_e);

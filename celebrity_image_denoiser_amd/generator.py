@@ -387,7 +387,7 @@ class DenoiseGenerator(nn.Module):
 
     @property
     def tail_algo(self) -> str:
-        """"fused" (default: the last layer's channel contraction runs inside upconv1[0]'s Winograd kernel; with conv_algo
+        """"fused" (default: the last layer's channel contraction runs inside upconv1[0]'s kernel — Winograd or split16; with conv_algo
         "direct" or compute_dtype "f16" it behaves as "bands"), "bands" (separate row-band kernel, images up to 128 pixels
         wide) or "tiles" (round 1's tiled kernel).  Same function; all go through the parity tests."""
         a = ctypes.c_int()

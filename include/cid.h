@@ -186,7 +186,8 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  *                       1e-6): 4.9 / 7.7 where the exact-fp32 direct kernel has 4.2 / 6.3, the Winograd default 2.2 / 4.0 and ATen fp32 2.2 / 2.5 — the least accurate
  *                       of the four algorithms, inside the 1e-5 contract with the thinnest margin.  It passes every 1e-5 parity test of the suite, but its arithmetic type is
  *                       "fp32 operands as two halfs, fp16 MFMA, fp32 accumulate": the default and the headline benchmark stay on CID_ALGO_WINOGRAD42.
- *                       The last layer runs as CID_TAIL_BANDS / CID_TAIL_TILES under this algorithm (no fused contraction).
+ *                       CID_TAIL_FUSED works under it: upconv1[2]'s contraction runs in the same split-operand arithmetic in upconv1[0]'s epilogue and
+ *                       leaves the 27 fp32 planes k_conv_tail_z sums.
  * (value 1 was round 1's first Winograd kernel, removed: same bits as WINOGRAD64, slower.)
  * No reference counterpart (the reference leaves the choice to ATen/oneDNN/cuDNN).
  */

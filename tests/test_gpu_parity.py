@@ -29,7 +29,7 @@ def _need_gpu():
 
 def _default_tail(algo):
     """The last-layer form each 3x3 algorithm is tested with by default: the fused contraction needs a Winograd kernel in front of it."""
-    return {"direct": "tiles", "split16": "bands"}.get(algo, "fused")
+    return {"direct": "tiles"}.get(algo, "fused")
 
 
 @pytest.fixture(scope="module", params=["winograd42", "winograd64", "direct", "split16"])
@@ -441,7 +441,7 @@ def test_padded_forward_equals_pad_in_memory_bit_for_bit(models):
     m = models["hot"]
     x, _, noisy = synth.make_batch(3, 37, 50, first_index=7100)
     xd, ud = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(noisy).to("cuda:0")
-    tails = ("tiles",) if m.conv_algo == "direct" else ("bands", "tiles") if m.conv_algo == "split16" else ("fused", "bands", "tiles")
+    tails = ("tiles",) if m.conv_algo == "direct" else ("fused", "bands", "tiles")
     for pads in ((1, 1, 2, 1), (0, 3, 1, 0), (5, 2, 5, 5), (0, 0, 0, 0)):   # (left, top, right, bottom): 40x53, 40x51, 44x60 (37+7, 50+10), 37x50
         left, top, right, bottom = pads
         hp, wp = 37 + top + bottom, 50 + left + right
@@ -1024,6 +1024,15 @@ def test_split16_wide_images_batch_independence_and_error_budget(weight_sets):
 
     names = [_lib.lib().cid_launch_kernel(m._cid, i).decode() for i in range(12)]
     assert sum(n.startswith("k_conv3x3_h16<") and n.endswith("true>") for n in names) == 8 and names[0].startswith("k_conv_head") and names[9].startswith("k_convt_s32")
+    # the fused last layer under this algorithm (the default form): upconv1[2]'s contraction in split-operand arithmetic inside upconv1[0]'s kernel, 27 fp32 planes to k_conv_tail_z;
+    # same contract, and the launch table says so
+    m.tail_algo = "fused"
+    yf = m(xd)
+    assert float(np.abs(yf[:8].cpu().numpy() - ref8).max()) <= TOL and float((yf - yb).abs().max()) <= TOL
+    assert _lib.lib().cid_launch_kernel(m._cid, 10).decode() == "k_conv3x3_h16<128, 64, 0, true, false, true>" and _lib.lib().cid_launch_kernel(m._cid, 11).decode().startswith("k_conv_tail_z<")
+    for shape in ((1, 250, 300),):
+        x2, _, _ = synth.make_batch(shape[0], shape[1], shape[2], first_index=4243)
+        assert float(np.abs(_run(m, x2) - torch_oracle.forward(sd, x2).numpy()).max()) <= TOL
 
 
 def test_config3_full_size_256x256_batch_256(weight_sets):
