@@ -27,7 +27,7 @@ for wset in ("default", "hot"):
         rows = [("ATen fp32 (CPU)", torch_oracle.forward(sd, x).numpy())]
         for algo in ("winograd42", "winograd64", "direct", "split16"):
             m.conv_algo = algo
-            m.tail_algo = {"direct": "tiles", "split16": "bands"}.get(algo, "fused")
+            m.tail_algo = {"direct": "tiles"}.get(algo, "fused")
             rows.append((algo + (" (opt-in)" if algo == "split16" else " (default)" if algo == "winograd42" else ""), m(torch.from_numpy(x).to("cuda:0")).cpu().numpy()))
         for name, y in rows:
             print("%-8s %-12s %-22s %10.3f %10.3f %10.4f" % ((wset, iname, name) + stats(y, ref64)), flush=True)

@@ -183,7 +183,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  *                       taken as hi + lo with hi = half(x), lo = half(x - hi) (22 bits of mantissa), every product as hi*hi + hi*lo + lo*hi on
  *                       v_mfma_f32_16x16x32_f16 with fp32 accumulators (lo*lo, 2^-22 relative, dropped).  9 multiplies per pixel (direct form), each on three
  *                       half products.  Measured against a float64 evaluation (profiles/r04_accuracy_study.txt, He-gain weights, faces / white noise, units of
- *                       1e-6): 4.9 / 7.7 where the exact-fp32 direct kernel has 4.2 / 6.3, the Winograd default 2.2 / 4.0 and ATen fp32 2.2 / 2.5 — the least accurate
+ *                       1e-6): 5.2 / 7.7 where the exact-fp32 direct kernel has 4.2 / 6.3, the Winograd default 2.2 / 4.0 and ATen fp32 2.2 / 2.5 — the least accurate
  *                       of the four algorithms, inside the 1e-5 contract with the thinnest margin.  It passes every 1e-5 parity test of the suite, but its arithmetic type is
  *                       "fp32 operands as two halfs, fp16 MFMA, fp32 accumulate": the default and the headline benchmark stay on CID_ALGO_WINOGRAD42.
  *                       CID_TAIL_FUSED works under it: upconv1[2]'s contraction runs in the same split-operand arithmetic in upconv1[0]'s epilogue and
