@@ -50,9 +50,9 @@ const char* kWino64KernelNames[NL] = {
     "k_wino64_conv<128, 128, false,", nullptr, "k_wino64_conv<128, 64, false,", nullptr,
 };
 const char* kSplitKernelNames[NL] = {   // conv_algo = "split16": the eight 3x3 layers on k_conv3x3_h16<..., F32IO = true>; everything else as the direct configuration
-    nullptr, "k_conv3x3_h16<64, 64, 1, false, false, true>", "k_conv3x3_h16<64, 128, 0, false, false, true>", "k_conv3x3_h16<128, 128, 1, false, false, true>",
-    "k_conv3x3_h16<128, 256, 0, false, false, true>", "k_conv3x3_h16<256, 256, 0, false, false, true>", nullptr, "k_conv3x3_h16<256, 128, 0, false, false, true>",
-    "k_conv3x3_h16<128, 128, 0, false, false, true>", nullptr, "k_conv3x3_h16<128, 64, 0, false, false, true>", nullptr,
+    nullptr, "k_conv3x3_h16<64, 64, 1, false, false, true,", "k_conv3x3_h16<64, 128, 0, false, false, true,", "k_conv3x3_h16<128, 128, 1, false, false, true,",
+    "k_conv3x3_h16<128, 256, 0, false, false, true,", "k_conv3x3_h16<256, 256, 0, false, false, true,", nullptr, "k_conv3x3_h16<256, 128, 0, false, false, true,",
+    "k_conv3x3_h16<128, 128, 0, false, false, true,", nullptr, "k_conv3x3_h16<128, 64, 0, false, false, true,", nullptr,
 };
 const char* kWino42KernelNames[NL] = {
     nullptr, "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
@@ -533,6 +533,13 @@ hipError_t launch_conv3x3(int algo, hipStream_t s, const float* blob, int layer,
         const TileGrid g = tiles_for(N, Hc, Wc);
         a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
         a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty); a.walk = 0;
+        if constexpr (COUT >= 128) {   // two column blocks per workgroup from one staging of the input tile (conv_kernels_f16.h, PAIR)
+            static const int pair = env_wg_per_cu("CID_SPLIT_PAIR", 1, 1);   // measurement aid: 0 = one column block per workgroup (same box: the six launches +8 % slower, profiles/r04_ab_split16_pair.txt)
+            if (pair) {
+                hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, false, false, true, true>), dim3(8 * g.per_xcd * (COUT / NTILE / 2)), dim3(THREADS), 0, s, a);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, MODE, false, false, true>), dim3(8 * g.per_xcd * (COUT / NTILE)), dim3(THREADS), 0, s, a);
         return hipGetLastError();
     }
@@ -1055,7 +1062,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i) {
         return kHalfKernelNames[i];
     }
     if (h && h->algo == CID_ALGO_SPLIT16) {
-        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true, false, true>" : "k_conv_tail_z<";
+        if (i >= 10 && fused_tail_active(h)) return i == 10 ? "k_conv3x3_h16<128, 64, 0, true, false, true," : "k_conv_tail_z<";
         return kSplitKernelNames[i] ? kSplitKernelNames[i] : kKernelNames[i];
     }
     if (h && h->algo == CID_ALGO_WINOGRAD42 && kWino42KernelNames[i]) return kWino42KernelNames[i];

@@ -505,8 +505,11 @@ __device__ __forceinline__ void h16_zout_epilogue_f32(const Args& a, f32x4* stag
 //     accumulators it measures faster than walking on every layer (profiles/r04_ab_f16_walk_vs_not.txt), and as a compile-time fact it removes the
 //     next-item decode, the prefetch under the last sub-step and the item boundary from the code.  WALK = true (cid_debug_half_workgroups_per_cu > 0)
 //     stays a tested option with the same bits.
-template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false, bool F32IO = false>
+template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false, bool F32IO = false, bool PAIR = false>
 __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const GemmConvArgsH a) {
+    // PAIR (F32IO only): one workgroup computes TWO 64-channel column blocks of its tile from one staging of the input — the hi / lo planes of a chunk serve nine sub-steps into
+    // `acc` (block 2 nbp) and nine into `acc2` (block 2 nbp + 1): half the loads, conversions, LDS writes and chunk seams per MFMA, half the workgroups.
+    static_assert(!PAIR || (F32IO && !ZOUT && !WALK && COUT % 128 == 0), "PAIR: split16 layers with at least two column blocks");
 #ifndef CID_EXPERIMENTS
     static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
@@ -534,8 +537,9 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
     __shared__ f32x4 lds[LDS_SLOTS];
 
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    int local = (WALK && a.walk) ? slot0 : slot0 / NB;                    // tile index inside the XCD group (k_wino42_conv)
-    int nb = (WALK && a.walk) ? 0 : slot0 - local * NB;
+    constexpr int NBW = PAIR ? NB / 2 : NB;                               // workgroups per tile
+    int local = (WALK && a.walk) ? slot0 : slot0 / NBW;                   // tile index inside the XCD group (k_wino42_conv)
+    int nb = (WALK && a.walk) ? 0 : (slot0 - local * NBW) * (PAIR ? 2 : 1);   // PAIR: the first of the workgroup's two column blocks
     {
         const int mt = xcd * a.tiles_per_xcd + local;
         if (!(mt < a.tiles_total && local < a.tiles_per_xcd)) return;
@@ -655,7 +659,7 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
     f32x4 acc[2][2][4];                                                   // [row m][pixel half pg][channel group cg]
     int wbase = 0, zs = 0;                                                // this item's B offset (bytes) and an opaque zero, renewed per item
     // one sub-step = one tap column dx of one chunk: A rows 0..3 of the wave (row r feeds output row m at dy = r - m), 12 B quads
-    auto substep = [&](auto first_tag, auto last_tag, int g, int dx, int req_ck = -1) {
+    auto substep_on = [&](auto& A, auto first_tag, auto last_tag, int g, int dx, int req_ck) {   // A: the accumulator set the sub-step adds to
         constexpr bool FIRST = decltype(first_tag)::value;    // first sub-step of an item: the accumulators start from zero
         constexpr bool LAST = decltype(last_tag)::value;      // last one: fetch the NEXT item's first B sub-chunk and halo chunk instead
         const f16x8* bq = ldsh + (g & 1) * BSUB + lane;
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
 #pragma unroll
                     for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], acc[m][pg][cg], 0, 0, 0);
+                        for (int cg = 0; cg < 4; ++cg) A[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], A[m][pg][cg], 0, 0, 0);
             return;
         }
 #pragma unroll
@@ -715,13 +719,14 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
                     for (int cg = 0; cg < 4; ++cg) {
                         if (FIRST && dy == 0) {
                             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], zero, 0, 0, 0);
+                            A[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], zero, 0, 0, 0);
                         } else {
-                            acc[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], acc[m][pg][cg], 0, 0, 0);
+                            A[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[m + dy][pg], bf[dy][cg], A[m][pg][cg], 0, 0, 0);
                         }
                     }
         }
     };
+    auto substep = [&](auto first_tag, auto last_tag, int g, int dx, int req_ck = -1) { substep_on(acc, first_tag, last_tag, g, dx, req_ck); };
     auto seam = [&]() {   // between sub-steps of one chunk: the next B sub-chunk has landed in every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -750,7 +755,40 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
 #ifdef H16_TRACE
         tr_lap(tr_bnd);     // prologue of the first item / boundary of the later ones
 #endif
-        if constexpr (F32IO) {   // nine sub-steps per 32-channel chunk — tap columns 0..2 on the hi planes against hi_w, again against lo_w, then on the
+        if constexpr (PAIR) {
+            // sub-step s of the sequence reads B buffer s & 1; which packed sub-chunk of which column block the NEXT one needs goes through `wbase` (dma_b fetches wbase + (s + 1) sub-chunks)
+            const int wbA = wbase, wbB = wbase + NSUB * (BSUB * 16);
+            auto aim = [&](int wb, int packed_next, int s_next) { wbase = wb + (packed_next - s_next) * (BSUB * 16); };
+            auto dxof = [&](int j) { return j >= 6 ? j - 6 + HALO_SLOTS : j >= 3 ? j - 3 : j; };
+            f32x4 acc2[2][2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) { acc[m][pg][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m][pg][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int ck = 0; ck < NCHUNK; ++ck) {
+                for (int j = 0; j < 9; ++j) {            // column block A on this chunk's planes
+                    const int q = 18 * ck + j;
+                    if (j < 8) aim(wbA, 9 * ck + j + 1, q + 1); else aim(wbB, 9 * ck, q + 1);
+                    substep_on(acc, F{}, F{}, q, dxof(j), -1);
+                    seam();
+                }
+                const int jend = ck + 1 < NCHUNK ? 9 : 8;
+                for (int j = 0; j < jend; ++j) {         // column block B; the next chunk is requested in its sub-step 7
+                    const int q = 18 * ck + 9 + j;
+                    if (j < 8) aim(wbB, 9 * ck + j + 1, q + 1); else aim(wbA, 9 * (ck + 1), q + 1);
+                    const int req = (j == 7 && ck + 1 < NCHUNK) ? ck + 1 : -1;
+                    substep_on(acc2, F{}, F{}, q, dxof(j), req);
+                    if (j == 8) chunk_seam(); else if (req >= 0) seam_keep_halo(); else seam();
+                }
+            }
+            wbase = wbA;
+            substep_on(acc2, F{}, T{}, 18 * NCHUNK - 1, 2 + HALO_SLOTS, -1);
+            int lane_p;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lane_p) : "v"(tid & 63));
+            h16_epilogue_f32<COUT, MODE>(a, acc2, *reinterpret_cast<const f32x4*>(a.bias + cobase + NTILE + 4 * c16 + zs), n, y0, x0, wave, lane_p, cobase + NTILE);
+        } else if constexpr (F32IO) {   // nine sub-steps per 32-channel chunk — tap columns 0..2 on the hi planes against hi_w, again against lo_w, then on the
             // lo planes against hi_w; the packed weights hold the sub-chunks in this order, so sub-step q reads sub-chunk q.  The next chunk is requested in sub-step 7.
             static_assert(!WALK, "one item per workgroup");
             substep(T{}, F{}, 0, 0); seam();

@@ -446,7 +446,7 @@ def launch_table(n: int, h: int, w: int, model: "DenoiseGenerator" = None):
         _lib.check(None, L.cid_launch_work(i, n, h, w, ctypes.byref(f0), ctypes.byref(b0)))
         kern = L.cid_launch_kernel(handle, i).decode()
         own = min(f.value, f0.value)                       # the launch's own layer (0 for a launch that only sums)
-        split = kern.startswith("k_conv3x3_h16") and kern.rstrip().endswith("true>")      # conv_algo "split16": three fp16-MFMA products per multiply
+        split = kern.startswith("k_conv3x3_h16<") and len(kern.split(",")) > 5 and kern.split(",")[5].strip().startswith("true")      # conv_algo "split16" (template flag F32IO): three fp16-MFMA products per multiply
         executed = own * (3.0 if split else 24.0 / 72.0 if "wino42" in kern else 16.0 / 36.0 if "wino" in kern else 1.0) + (f.value - own)
         rows.append((L.cid_launch_name(i).decode(), kern, f.value, b.value, executed))
     return rows

@@ -1023,13 +1023,13 @@ def test_split16_wide_images_batch_independence_and_error_budget(weight_sets):
     from celebrity_image_denoiser_amd import _lib
 
     names = [_lib.lib().cid_launch_kernel(m._cid, i).decode() for i in range(12)]
-    assert sum(n.startswith("k_conv3x3_h16<") and n.endswith("true>") for n in names) == 8 and names[0].startswith("k_conv_head") and names[9].startswith("k_convt_s32")
+    assert sum(n.startswith("k_conv3x3_h16<") and n.endswith(", false, false, true,") for n in names) == 8 and names[0].startswith("k_conv_head") and names[9].startswith("k_convt_s32")
     # the fused last layer under this algorithm (the default form): upconv1[2]'s contraction in split-operand arithmetic inside upconv1[0]'s kernel, 27 fp32 planes to k_conv_tail_z;
     # same contract, and the launch table says so
     m.tail_algo = "fused"
     yf = m(xd)
     assert float(np.abs(yf[:8].cpu().numpy() - ref8).max()) <= TOL and float((yf - yb).abs().max()) <= TOL
-    assert _lib.lib().cid_launch_kernel(m._cid, 10).decode() == "k_conv3x3_h16<128, 64, 0, true, false, true>" and _lib.lib().cid_launch_kernel(m._cid, 11).decode().startswith("k_conv_tail_z<")
+    assert _lib.lib().cid_launch_kernel(m._cid, 10).decode() == "k_conv3x3_h16<128, 64, 0, true, false, true," and _lib.lib().cid_launch_kernel(m._cid, 11).decode().startswith("k_conv_tail_z<")
     for shape in ((1, 250, 300),):
         x2, _, _ = synth.make_batch(shape[0], shape[1], shape[2], first_index=4243)
         assert float(np.abs(_run(m, x2) - torch_oracle.forward(sd, x2).numpy()).max()) <= TOL
