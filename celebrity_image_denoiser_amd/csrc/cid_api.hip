@@ -51,8 +51,8 @@ const char* kWino64KernelNames[NL] = {
 };
 const char* kSplitKernelNames[NL] = {   // conv_algo = "split16": the eight 3x3 layers on k_conv3x3_h16<..., F32IO = true>; everything else as the direct configuration
     nullptr, "k_conv3x3_h16<64, 64, 1, false, false, true,", "k_conv3x3_h16<64, 128, 0, false, false, true,", "k_conv3x3_h16<128, 128, 1, false, false, true,",
-    "k_conv3x3_h16<128, 256, 0, false, false, true,", "k_conv3x3_h16<256, 256, 0, false, false, true,", nullptr, "k_conv3x3_h16<256, 128, 0, false, false, true,",
-    "k_conv3x3_h16<128, 128, 0, false, false, true,", nullptr, "k_conv3x3_h16<128, 64, 0, false, false, true,", nullptr,
+    "k_conv3x3_h16<128, 256, 0, false, false, true,", "k_conv3x3_h16<256, 256, 0, false, false, true,", "k_conv3x3_h16<256, 128, 2, false, false, true,", "k_conv3x3_h16<256, 128, 0, false, false, true,",
+    "k_conv3x3_h16<128, 128, 0, false, false, true,", "k_conv3x3_h16<128, 64, 2, false, false, true,", "k_conv3x3_h16<128, 64, 0, false, false, true,", nullptr,
 };
 const char* kWino42KernelNames[NL] = {
     nullptr, "k_wino42_conv<64, 64, true,", "k_wino42_conv<64, 128, false,", "k_wino42_conv<128, 128, true,",
@@ -111,6 +111,8 @@ struct BlobLayout {
             s_off[l] = o;
             if (kLayers[l].kind == CONV) o = align_up(o + ((size_t)kLayers[l].cin * kLayers[l].cout * 27 + 1) / 2, 64);
         }
+        for (int l = 0; l < NL; ++l)   // split16: the two transposed convolutions' hi | lo | hi pieces, [block = (tap, 64 channels)][chunk][piece][cg][lane][8] halfs (12 halfs per weight)
+            if (kLayers[l].kind == CONVT) { s_off[l] = o; o = align_up(o + ((size_t)kLayers[l].cin * kLayers[l].cout * 12 + 1) / 2, 64); }
         hzs_off = o; o = align_up(o + 2 * 2 * 2 * 64 * 8 / 2, 64);   // split16, fused last layer: upconv1[2] as A fragments [hi | lo][2 row tiles][2 k-steps][64 lanes][8] halfs
         total = o;
     }
@@ -572,6 +574,22 @@ hipError_t launch_layer(cid_handle_t h, hipStream_t s, const float* blob, int la
                         float* out, int out_ps, int out_coff, int Hc, int Wc, int Hs, int Ws, float* pool, int N) {
     if (h->dtype == CID_DTYPE_F16)
         return launch_gemm_h<CIN, COUT, MODE>(s, blob, layer, in, Hin, Win, in_ps, out, out_ps, out_coff, Hc, Wc, Hs, Ws, pool, N);
+    if constexpr (MODE == 2) {
+        static const int split_t = env_wg_per_cu("CID_SPLIT_CONVT", 1, 1);   // measurement aid: 0 = the transposed convolutions stay on the fp32-MFMA kernels under conv_algo "split16"
+        if (h->algo == CID_ALGO_SPLIT16 && split_t) {
+            // ConvTranspose2d(k=2, s=2) in the split-operand form: (tap, 64 channels) column blocks, two per workgroup, over 8x32-pixel tiles of the INPUT
+            if (in_ps != CIN) return hipErrorInvalidValue;
+            GemmConvArgsH a;
+            a.in = reinterpret_cast<const _Float16*>(in); a.w = reinterpret_cast<const _Float16*>(blob + kBlob.s_off[layer]); a.bias = blob + kBlob.b_off[layer];
+            a.out = reinterpret_cast<_Float16*>(out); a.pool = nullptr;
+            a.N = N; a.Hin = Hin; a.Win = Win; a.in_ps = in_ps; a.Hc = Hc; a.Wc = Wc; a.Hs = Hs; a.Ws = Ws; a.out_ps = out_ps; a.out_coff = out_coff;
+            const TileGrid g = tiles_for(N, Hc, Wc);
+            a.tiles_x = g.tx; a.tiles_y = g.ty; a.tiles_total = g.total; a.tiles_per_xcd = g.per_xcd;
+            a.rcp_x = tile_rcp(g.tx); a.rcp_xy = tile_rcp(g.tx * g.ty); a.walk = 0;
+            hipLaunchKernelGGL((k_conv3x3_h16<CIN, COUT, 2, false, false, true, true>), dim3(8 * g.per_xcd * (4 * COUT / NTILE / 2)), dim3(THREADS), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (MODE == 2 && CIN == 128) {   // up1: streaming form, persistent workgroups (two per CU) over runs of TP input pixels
         using CG = ConvTGeom32<CIN, COUT>;
         GemmConvArgs a;
@@ -830,6 +848,17 @@ int cid_set_weight(cid_handle_t h, const char* key, const float* data, const int
                 const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
                 const size_t at = (((size_t)t * 2 + ks) * 64 + kga * 16 + (row & 15)) * 8 + e;
                 hzs[at] = hi; hzs[4 * 64 * 8 + at] = lo;
+            });
+        }
+        if (L.kind == CONVT) {   // split-operand pieces of a transposed convolution (k_conv3x3_h16<..., 2, ., ., F32IO, PAIR>): piece p = 0 hi_w, 1 lo_w, 2 hi_w again (met by lo_x)
+            _Float16* sp = reinterpret_cast<_Float16*>(h->staging.data() + kBlob.s_off[l]);
+            const int cbs = L.cout / 64, nchunk = L.cin / 32;
+            for_each_weight(L, [&](int co, int ci, int kh, int kw) {
+                const float v = data[ref_index(L, co, ci, kh, kw)];
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                const int blk = (kh * 2 + kw) * cbs + (co >> 6), cg = co & 3, c = (co >> 2) & 15, ck = ci >> 5, kg = (ci >> 3) & 3, e = ci & 7;
+                for (int p = 0; p < 3; ++p)
+                    sp[((((((size_t)blk * nchunk + ck) * 3 + p) * 4 + cg) * 64) + kg * 16 + c) * 8 + e] = p == 1 ? lo : hi;
             });
         }
         if (L.kind == CONV) {   // split-operand pieces (conv_algo = "split16")

@@ -401,6 +401,40 @@ __device__ __forceinline__ void h16_zout_epilogue(const Args& a, f32x4* stage, f
         }
 }
 
+// F32IO, MODE 2 (the transposed convolutions under conv_algo = "split16"): column block `blk` = (tap = blk / (COUT / 64), 64-channel block blk % (COUT / 64)); the wave's input pixel
+// (y, x) becomes output pixel (2y + kh, 2x + kw) of the [2 Hc][2 Wc] tensor (out_ps floats per pixel, out_coff: the cat slice).  Bias, no activation (app.py:65,73,89,96).
+template <int COUT, typename Args>
+__device__ __forceinline__ void h16_epilogue_t32(const Args& a, f32x4 (&acc)[2][2][4], int n, int y0, int x0, int wave, int lane, int blk) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    constexpr int CB = COUT / 64;
+    const int tap = blk / CB, cb = blk - tap * CB, kh = tap >> 1, kw = tap & 1;
+    const int c16 = lane & 15, kg = lane >> 4, pb = (0xa802 >> (4 * kg)) & 15;
+    const int Ho = 2 * a.Hc, Wo = 2 * a.Wc;
+    const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + 4 * c16);
+    auto store16 = [](f32x4 v, const __amdgpu_buffer_rsrc_t& rsrc, unsigned vo, unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rsrc, vo, soff, 0);     // partial lines: the L2 merges the four taps' stores (not non-temporal)
+        asm volatile("s_nop 3" ::"v"(v) : "memory");
+    };
+    const unsigned long long p = (unsigned long long)(reinterpret_cast<float*>(a.out) + (size_t)n * Ho * Wo * a.out_ps);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, Ho * Wo * a.out_ps * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)(((2 * pb + kw) * a.out_ps + 4 * c16) * 4);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = __builtin_amdgcn_readfirstlane(y0 + 2 * wave + m);
+        const unsigned row_off = (unsigned)((((2 * y + kh) * Wo + 2 * x0) * a.out_ps + a.out_coff + cb * 64) * 4);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dp = 16 * pg + (r & 1) + 4 * (r >> 1);
+                const f32x4 v = {acc[m][pg][0][r] + bias_v[0], acc[m][pg][1][r] + bias_v[1], acc[m][pg][2][r] + bias_v[2], acc[m][pg][3][r] + bias_v[3]};
+                const unsigned vo = (y < a.Hc && x0 + pb + dp < a.Wc) ? lane_off : 0x7ffffff0u;
+                store16(v, ro, vo, row_off + (unsigned)(2 * dp * a.out_ps * 4));
+            }
+    }
+}
+
 // ZOUT epilogue of k_conv3x3_h16<128, 64, 0, ZOUT, ., F32IO> (conv_algo = "split16"): upconv1[2]'s 64 -> 27 contraction per tap (as h16_zout_epilogue above) in the
 // split-operand arithmetic of the layer itself.  The wave's finished 2 rows x 32 pixels x 64 channels (bias + ReLU, fp32) are split into hi / lo halfs and staged in a
 // wave-private LDS area (hi: [row][pixel][8 slots of 8 channels], slot XOR (pixel & 7); lo: the same 8 KiB further), the weights' hi / lo pieces come as A fragments
@@ -509,11 +543,11 @@ template <int CIN, int COUT, int MODE, bool ZOUT = false, bool WALK = false, boo
 __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const GemmConvArgsH a) {
     // PAIR (F32IO only): one workgroup computes TWO 64-channel column blocks of its tile from one staging of the input — the hi / lo planes of a chunk serve nine sub-steps into
     // `acc` (block 2 nbp) and nine into `acc2` (block 2 nbp + 1): half the loads, conversions, LDS writes and chunk seams per MFMA, half the workgroups.
-    static_assert(!PAIR || (F32IO && !ZOUT && !WALK && COUT % 128 == 0), "PAIR: split16 layers with at least two column blocks");
+    static_assert(!PAIR || (F32IO && !ZOUT && !WALK && (MODE == 2 || COUT % 128 == 0)), "PAIR: split16 layers with at least two column blocks");
 #ifndef CID_EXPERIMENTS
     static_assert(H16_ABLATE == 0, "ablation variants are built only by csrc/tools (-DCID_EXPERIMENTS)");
 #endif
-    static_assert(MODE == 0 || MODE == 1, "3x3 layers only");
+    static_assert(MODE == 0 || MODE == 1 || (MODE == 2 && F32IO && PAIR), "3x3 layers; MODE 2 (2x2 stride-2 transposed convolution) only in the split-operand form");
     static_assert(!ZOUT || (COUT == 64 && MODE == 0), "the fused last layer contracts the 64 channels of ONE column block");
     constexpr int LW = TILE_W + 2, LH = TILE_H + 2, LPIX = LW * LH;       // 340
     constexpr int PLANE = LPIX;                                           // slots per k-group plane; 340 = 4 mod 16, see above
@@ -521,8 +555,8 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
     // F32IO (conv_algo = "split16" of the fp32 path): CIN counts FP32 channels; a chunk = 32 of them = 128 bytes per pixel in 8 pieces of 16 bytes, split into a hi and a lo set of planes
     // while staging; nine sub-steps per chunk (hi_x . hi_w, hi_x . lo_w, lo_x . hi_w for each tap column), the host packs the weight sub-chunks in that order
     constexpr int NSLOT = LPIX * (F32IO ? 8 : 4), NLOAD = (NSLOT + THREADS - 1) / THREADS;   // 6 (11)
-    constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * (F32IO ? 9 : 3);
-    constexpr int NB = COUT / NTILE;
+    constexpr int NCHUNK = CIN / 32, NSUB = NCHUNK * (MODE == 2 ? 1 : F32IO ? 9 : 3);   // packed 12-KiB weight sub-chunks per column block
+    constexpr int NB = (MODE == 2 ? 4 * COUT : COUT) / NTILE;            // column blocks; MODE 2: (tap, 64 output channels)
     constexpr int BSUB = 3 * 4 * 64;                                      // quads of one B sub-chunk (column dx: 3 dy x 4 cg), 12 KiB
     // (r4) ... and the k-group planes lie at 0, PLANE, 2 PLANE + 2, 3 PLANE + 2: the pairs (0,1) and (2,3) that share a ds_read_b128 service group stay
     // 4 (mod 16) slots apart (reads conflict-free as before), while the four plane origins are now 0, 4, 2, 6 (mod 8) — the eight lanes of a
@@ -604,7 +638,7 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
         }
     };
     // B sub-chunk g = 3 ck + dx: 12 quads of 1 KiB, lane-contiguous in global memory -> LDS-DMA, three per wave, no registers
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * 9 * 2 * (F32IO ? 3 : 1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CIN * COUT * (MODE == 2 ? 4 : 9) * 2 * (F32IO ? 3 : 1), 0x00020000);
     const unsigned vlane = lane * 16;
     auto dma_b = [&](int wb, int g) {   // wb = byte offset of the item's column block in the packed weights
         if ((H16_ABLATE & 1) && abl_on) return;
@@ -727,6 +761,44 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
         }
     };
     auto substep = [&](auto first_tag, auto last_tag, int g, int dx, int req_ck = -1) { substep_on(acc, first_tag, last_tag, g, dx, req_ck); };
+    // MODE 2 (ConvTranspose2d(k=2, s=2) in the split-operand form): a column block is (tap, 64 output channels), an output pixel (2y + kh, 2x + kw) a plain 1x1 product of
+    // input pixel (y, x): per 32-channel chunk and block ONE sub-step of 48 MFMAs — the wave's own two rows (the halo tile's centre) from the hi planes against hi_w and
+    // lo_w, from the lo planes against hi_w; the 12-KiB weight sub-chunk holds those three pieces where a 3x3 sub-chunk holds three tap rows.
+    auto substep_t = [&](auto& A, auto last_tag, int g, int req_ck) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const f16x8* bq = ldsh + (g & 1) * BSUB + lane;
+        const f16x8* aq = ldsh + abase + LW + 1;                    // centre of the halo tile: row + 1, column + 1
+        if (!LAST) {
+            dma_b(wbase, g + 1);
+            if (req_ck >= 0) request_halo(rsrc_in, req_ck, zs);
+        }
+        f16x8 ax[2][2], bf[2][4];                                   // weights one piece ahead; the pixel fragments of the plane set in use (hi for pieces 0-1, lo for piece 2)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) bf[0][cg] = bq[cg * 64];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) ax[m][pg] = aq[m * LW + pg * 16];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (p < 2) {
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) bf[(p + 1) & 1][cg] = bq[((p + 1) * 4 + cg) * 64];
+            }
+            if (p == 2) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pg = 0; pg < 2; ++pg) ax[m][pg] = aq[m * LW + pg * 16 + HALO_SLOTS];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) A[m][pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[m][pg], bf[p & 1][cg], A[m][pg][cg], 0, 0, 0);
+        }
+    };
     auto seam = [&]() {   // between sub-steps of one chunk: the next B sub-chunk has landed in every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -751,11 +823,37 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         wbase = nb * NSUB * (BSUB * 16) + zs;
         const int cobase = nb * NTILE;
-        const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + cobase + 4 * c16 + zs);   // column c16 of group cg = channel 4 c16 + cg
+        const f32x4 bias_v = *reinterpret_cast<const f32x4*>(a.bias + (MODE == 2 ? 0 : cobase) + 4 * c16 + zs);   // column c16 of group cg = channel 4 c16 + cg (MODE 2: its epilogue loads its own)
 #ifdef H16_TRACE
         tr_lap(tr_bnd);     // prologue of the first item / boundary of the later ones
 #endif
-        if constexpr (PAIR) {
+        if constexpr (MODE == 2) {
+            // two column blocks per workgroup (PAIR): per chunk one sub-step into `acc` (block nb) and one into `acc2` (block nb + 1); sub-step s reads B buffer s & 1 and
+            // the DMA's base offset picks the block whose sub-chunk comes next
+            const int wbA = wbase, wbB = wbase + NSUB * (BSUB * 16);
+            auto aim = [&](int wb, int packed_next, int s_next) { wbase = wb + (packed_next - s_next) * (BSUB * 16); };
+            f32x4 acc2[2][2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) { acc[m][pg][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m][pg][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int ck = 0; ck + 1 < NCHUNK; ++ck) {
+                aim(wbB, ck, 2 * ck + 1);
+                substep_t(acc, F{}, 2 * ck, ck + 1); seam_keep_halo();
+                aim(wbA, ck + 1, 2 * ck + 2);
+                substep_t(acc2, F{}, 2 * ck + 1, -1);
+                chunk_seam();
+            }
+            aim(wbB, NCHUNK - 1, 2 * NCHUNK - 1);
+            substep_t(acc, F{}, 2 * NCHUNK - 2, -1); seam();
+            wbase = wbA;
+            substep_t(acc2, T{}, 2 * NCHUNK - 1, -1);
+            int lane_p;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lane_p) : "v"(tid & 63));
+            h16_epilogue_t32<COUT>(a, acc2, n, y0, x0, wave, lane_p, nb + 1);
+        } else if constexpr (PAIR) {
             // sub-step s of the sequence reads B buffer s & 1; which packed sub-chunk of which column block the NEXT one needs goes through `wbase` (dma_b fetches wbase + (s + 1) sub-chunks)
             const int wbA = wbase, wbB = wbase + NSUB * (BSUB * 16);
             auto aim = [&](int wb, int packed_next, int s_next) { wbase = wb + (packed_next - s_next) * (BSUB * 16); };
@@ -854,6 +952,8 @@ __global__ void __launch_bounds__(THREADS, F32IO ? 2 : 3) k_conv3x3_h16(const Ge
                 __syncthreads();   // every wave has read its last fragments: B buffer 1 and the halo planes become the staging area (32 KiB)
                 static_assert(4 * 512 <= LDS_SLOTS - BSUB, "z staging must fit behind B buffer 0 (the next item's first B sub-chunk lands there)");
                 h16_zout_epilogue(a, lds + BSUB, acc, bias_v, n, y0, x0, wave, lane_e);
+            } else if constexpr (F32IO && MODE == 2) {
+                h16_epilogue_t32<COUT>(a, acc, n, y0, x0, wave, lane_e, nb);
             } else if constexpr (F32IO) {
                 h16_epilogue_f32<COUT, MODE>(a, acc, bias_v, n, y0, x0, wave, lane_e, cobase);
             } else {

@@ -12,7 +12,7 @@ for wset in ("default", "hot"):
     x = (torch.rand((6, 3, 128, 134), generator=g) * 2 - 1).contiguous()
     ref64 = torch_oracle.forward(sd, x.numpy(), dtype=torch.float64).numpy() if "dtype" in torch_oracle.forward.__code__.co_varnames else None
     ref32 = torch_oracle.forward(sd, x.numpy()).numpy()
-    for algo in ("winograd42", "winograd64", "direct"):
+    for algo in ("winograd42", "winograd64", "direct", "split16"):
         m.conv_algo = algo; m.tail_algo = "tiles" if algo == "direct" else "fused"
         y = m(x.to("cuda:0")).cpu().numpy()
         print(wset, algo, "vs fp32 ATen", float(np.abs(y - ref32).max()), "vs fp64", None if ref64 is None else float(np.abs(y - ref64).max()), flush=True)

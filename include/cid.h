@@ -174,7 +174,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
 
 /*
  * Algorithm of the eight GEMM-shaped 3x3 convolutions (down1[2] ... upconv1[0]); head, tail and the
- * transposed convolutions are unaffected.  All compute the reference's nn.Conv2d(k=3,p=1) in fp32 (exact-fp32 MFMA):
+ * transposed convolutions are unaffected (except under CID_ALGO_SPLIT16, which runs the transposed convolutions in its own arithmetic too).  All compute the reference's nn.Conv2d(k=3,p=1) in fp32 (exact-fp32 MFMA):
  *   CID_ALGO_DIRECT     implicit GEMM, 9 taps: 9 multiplies per output pixel and (ci,co)
  *   CID_ALGO_WINOGRAD64 Winograd F(2x2,3x3): 4 multiplies per pixel (round 1's default)
  *   CID_ALGO_WINOGRAD42 Winograd F(4x2,3x3), tiles 4 wide x 2 high, interpolation points 0, +-3/4, +-3/2, inf: 3 multiplies
@@ -183,7 +183,7 @@ const char* cid_launch_kernel(cid_handle_t h, int i);
  *                       taken as hi + lo with hi = half(x), lo = half(x - hi) (22 bits of mantissa), every product as hi*hi + hi*lo + lo*hi on
  *                       v_mfma_f32_16x16x32_f16 with fp32 accumulators (lo*lo, 2^-22 relative, dropped).  9 multiplies per pixel (direct form), each on three
  *                       half products.  Measured against a float64 evaluation (profiles/r04_accuracy_study.txt, He-gain weights, faces / white noise, units of
- *                       1e-6): 5.2 / 7.7 where the exact-fp32 direct kernel has 4.2 / 6.3, the Winograd default 2.2 / 4.0 and ATen fp32 2.2 / 2.5 — the least accurate
+ *                       1e-6): 5.1 / 8.6 where the exact-fp32 direct kernel has 4.2 / 6.3, the Winograd default 2.2 / 4.0 and ATen fp32 2.2 / 2.5 — the least accurate
  *                       of the four algorithms, inside the 1e-5 contract with the thinnest margin.  It passes every 1e-5 parity test of the suite, but its arithmetic type is
  *                       "fp32 operands as two halfs, fp16 MFMA, fp32 accumulate": the default and the headline benchmark stay on CID_ALGO_WINOGRAD42.
  *                       CID_TAIL_FUSED works under it: upconv1[2]'s contraction runs in the same split-operand arithmetic in upconv1[0]'s epilogue and

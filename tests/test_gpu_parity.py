@@ -1023,7 +1023,9 @@ def test_split16_wide_images_batch_independence_and_error_budget(weight_sets):
     from celebrity_image_denoiser_amd import _lib
 
     names = [_lib.lib().cid_launch_kernel(m._cid, i).decode() for i in range(12)]
-    assert sum(n.startswith("k_conv3x3_h16<") and n.endswith(", false, false, true,") for n in names) == 8 and names[0].startswith("k_conv_head") and names[9].startswith("k_convt_s32")
+    # the eight 3x3 layers AND the two transposed convolutions run on the split-operand kernel; head and last layer are the fp32 path's own
+    assert sum(n.startswith("k_conv3x3_h16<") and n.endswith(", false, false, true,") for n in names) == 10 and names[0].startswith("k_conv_head")
+    assert names[6] == "k_conv3x3_h16<256, 128, 2, false, false, true," and names[9] == "k_conv3x3_h16<128, 64, 2, false, false, true,"
     # the fused last layer under this algorithm (the default form): upconv1[2]'s contraction in split-operand arithmetic inside upconv1[0]'s kernel, 27 fp32 planes to k_conv_tail_z;
     # same contract, and the launch table says so
     m.tail_algo = "fused"
