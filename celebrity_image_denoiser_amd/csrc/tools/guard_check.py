@@ -7,8 +7,8 @@ from celebrity_image_denoiser_amd import synth, _lib
 G = 1 << 20   # guard bytes on each side
 m = cid.load(synth.make_state_dict("hot"), device="cuda:0", strict=True)
 bad = 0
-for algo in ("winograd42", "winograd64", "direct"):
-    for dtype in ("f32", "f16"):
+for algo in ("winograd42", "winograd64", "direct", "split16"):
+    for dtype in (("f32",) if algo == "split16" else ("f32", "f16")):
         m.conv_algo, m.compute_dtype = algo, dtype
         for (n, h, w) in ((5, 128, 128), (3, 40, 72), (2, 21, 30), (1, 4, 4), (2, 130, 31), (600, 128, 128)):
             need = ctypes.c_size_t(); _lib.check(m._cid, _lib.lib().cid_workspace_bytes(n, h, w, ctypes.byref(need)))

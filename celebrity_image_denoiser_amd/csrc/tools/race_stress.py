@@ -16,7 +16,12 @@ for it in range(40):
     m.tail_algo = "bands"; c = m(x).clone(); c2 = m(x).clone()
     m.conv_algo, m.tail_algo = "winograd64", "fused"; e = m(x).clone(); e2 = m(x).clone()
     m.conv_algo, m.tail_algo = "direct", "tiles"; d = m(x).clone()
+    # the opt-in split-operand algorithm (fused last layer, two column blocks per workgroup, transposed convolutions included): run to run bit-equal, within 2e-5 of the default
+    m.conv_algo, m.tail_algo = "split16", "fused"; s1 = m(x).clone(); s2 = m(x).clone()
     torch.cuda.synchronize()
+    worst_s16 = max(globals().get("worst_s16", 0.0), float((s1 - a).abs().max()))
+    if not (torch.equal(s1, s2) and float((s1 - a).abs().max()) <= 2e-5):
+        bad += 1; print("split16 MISMATCH at iteration", it, tuple(x.shape), float((s1 - s2).abs().max()), float((s1 - a).abs().max()))
     # two runs of one configuration: bit-equal.  Two ALGORITHMS: each is within the 1e-5 contract of the exact result, so within 2e-5 of each
     # other (white-noise inputs on the He-gain weights are the worst case: F(4x2) against the direct kernel has reached 1.03e-5 here)
     if not (torch.equal(a, b) and torch.equal(c, c2) and torch.equal(e, e2) and float((a - c).abs().max()) <= 1e-5
@@ -36,5 +41,6 @@ for it in range(40):
     if not (torch.equal(h1, h2) and torch.equal(t1, t2) and float((h1 - t1).abs().max()) <= 2e-3 and float((h1 - a).abs().max()) <= 8e-3):
         bad += 1; print("fp16 MISMATCH at iteration", it, tuple(x.shape), float((h1 - h2).abs().max()), float((t1 - t2).abs().max()), float((h1 - t1).abs().max()), float((h1 - a).abs().max()))
 print("fp16 storage vs fp32 on white noise, worst over all iterations: fused last layer %.3e, separate last layer %.3e" % (worst_h16, worst_t16))
+print("split16 vs winograd42 on white noise, worst over all iterations: %.3e" % globals().get("worst_s16", 0.0))
 print("iterations with a mismatch:", bad)
 sys.exit(1 if bad else 0)
